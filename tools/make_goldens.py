@@ -1,0 +1,347 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors and the model fixture from the REAL reference code.
+
+Runs only in the build container (needs /root/reference).  Nothing here is imported by the
+product, the tests or the bench; the outputs are data files:
+
+  dragposer_amd/data/model_dancedb.npz   decoder/encoder tensors + dataset statistics + skeleton
+                                         (weights are CC BY-SA 4.0, see dragposer_amd/data/NOTICE)
+  tests/golden/{s1,s3,s4,es}.npz         inputs and expected outputs of DragPose.run()
+
+How the reference is driven (all reference code is executed from /root/reference, nothing is
+copied): the reference modules are imported with tools/pymotion_standin on sys.path (the
+un-vendored dependency upc-pymotion==0.1.10 is absent; the stand-in restates the four torch
+quaternion helpers the hot path calls).  For every synthetic frame the *real*
+``DragPose.run()`` (drag_pose.py:196-414) is executed: real Decoder, real loss()/FK, real
+autograd and real torch.optim.Adam.  The only substitutions are harness-side:
+  * the temporal predictor (weights missing from the mount: temporal.pt) is replaced by a stub
+    that returns the recipe's z_tgt, with means_latent=0 / stds_latent=1, so that
+    ``target_latent`` (drag_pose.py:294) is exactly the stored input z_tgt;
+  * ``set_initial_pose`` (encoder + randn) is bypassed: z0 / cur_rot are stored inputs.
+
+Synthetic recipe S: seed 1234, draw order Zs, Z0, ZT-noise, CR
+(+ Eb, perms for S4); targets = FK(decode(Zs), CR) at the tracked joints.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/python"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, "tools", "pymotion_standin"))
+sys.path.insert(0, os.path.join(REF, "src"))
+
+torch.set_num_threads(1)
+
+import drag_pose as ref_drag_pose  # noqa: E402  (reference)
+import train as ref_train  # noqa: E402  (reference)
+import utils as ref_utils  # noqa: E402  (reference)
+from generator_architecture import Generator_Model  # noqa: E402  (reference)
+from train_data import Train_Data  # noqa: E402  (reference)
+
+NJ = 22
+TRACK6 = [0, 3, 7, 13, 17, 21]
+TRACK3 = [13, 17, 21]
+
+
+def parse_bvh_skeleton(path):
+    """Own minimal BVH HIERARCHY reader: joint OFFSET rows (End Sites skipped) and parents."""
+    parents, offsets, stack = [], [], []
+    in_end_site = False
+    pending = None
+    with open(path) as f:
+        for line in f:
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "MOTION":
+                break
+            if tok[0] in ("ROOT", "JOINT"):
+                pending = len(parents)
+                parents.append(stack[-1] if stack else 0)
+                offsets.append(None)
+            elif tok[0] == "End":
+                in_end_site = True
+                pending = None
+            elif tok[0] == "{":
+                stack.append(pending if pending is not None else -1)
+            elif tok[0] == "}":
+                if stack.pop() == -1:
+                    in_end_site = False
+            elif tok[0] == "OFFSET" and not in_end_site:
+                offsets[stack[-1]] = [float(t) for t in tok[1:4]]
+    parents[0] = 0  # train.py:338
+    offsets = np.asarray(offsets, dtype=np.float32)
+    offsets[0] = 0.0  # train.py:340
+    return np.asarray(parents, dtype=np.int32), offsets
+
+
+class StubTemporal:
+    """Stands in for the missing temporal.pt: returns the recipe's z_tgt as the prediction."""
+
+    device = "cpu"
+
+    def __init__(self):
+        self.z_tgt = None
+
+    def eval(self):
+        return self
+
+    def __call__(self, input_latent, input_target_latent):
+        return self.z_tgt.reshape(1, 1, -1).clone()
+
+
+class RecordingDragPose(ref_drag_pose.DragPose):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.rec = []
+
+    def loss(self, *a, **k):
+        out = super().loss(*a, **k)
+        self.rec.append(
+            dict(
+                losses=[float(out[0]), float(out[1]), float(out[2])],
+                world_disp=out[4].detach().clone().reshape(3),
+                world_rot=out[6].detach().clone().reshape(4),
+                pos=out[7].detach().clone().reshape(NJ, 3),
+                rot=_FK_STASH["rot"].detach().clone().reshape(NJ, 3, 3),
+            )
+        )
+        return out
+
+
+_FK_STASH = {}
+
+
+def _recording_fk(rot, global_pos, offsets, parents):
+    pos, rotm = ref_utils.fk_rotmat(rot, global_pos, offsets, parents)
+    _FK_STASH["pos"], _FK_STASH["rot"] = pos, rotm
+    return pos, rotm
+
+
+ref_drag_pose.fk_rotmat = _recording_fk
+
+
+def build_reference(parents, weight_rounding=None):
+    td = Train_Data("cpu", ref_train.param, None)
+    gm = Generator_Model("cpu", ref_train.param, list(int(p) for p in parents), td)
+    ref_train.load_model(gm, os.path.join(REF, "models/model_dancedb/generator.pt"), td, "cpu")
+    if weight_rounding == "bf16":
+        # S4: every decoder *weight* tensor rounded to bf16 (biases, masks, unpool untouched)
+        with torch.no_grad():
+            dec = gm.autoencoder.decoder
+            dec.f_latent.weight.copy_(dec.f_latent.weight.to(torch.bfloat16).float())
+            for layer in dec.layers:
+                layer[1].weight.copy_(layer[1].weight.to(torch.bfloat16).float())
+    stub = StubTemporal()
+    drag = RecordingDragPose(gm, stub, torch.zeros(24), torch.ones(24), "cpu", "cpu")
+    return gm, td, drag, stub
+
+
+def reset_state(drag, z0, cur_rot):
+    """What set_initial_pose (drag_pose.py:47-64) leaves behind, with z0/cur_rot given."""
+    drag.current_global_pos = torch.zeros(1, 3, 1)
+    drag.current_global_rot = cur_rot.reshape(1, 4).clone()
+    drag.latent = z0.reshape(1, 24).clone().detach().requires_grad_()
+    drag.latent_buffer = torch.tile(drag.latent.detach(), (60, 1))
+    drag.displacement_buffer = torch.zeros(60, 3)
+    drag.heights_buffer = torch.zeros(60, 6)
+    drag.current_index = 0
+    drag.target_latent_buffer = None
+    drag.rec = []
+
+
+def forward_fk(drag, td, z, cur_rot, offsets):
+    """decode(z) -> FK via the reference's own loss() path; returns pos(22,3), rot(22,3,3)."""
+    reset_state(drag, z, cur_rot)
+    with torch.no_grad():
+        motion, disp = drag.decoder(drag.latent, td.mean_dqs, td.std_dqs)
+        drag.loss(
+            motion, disp,
+            torch.zeros(1, 1, 1, 3), torch.zeros(1, 1, 1, 3, 3), torch.zeros(24),
+            offsets, torch.tensor([0]), torch.ones(1, 2), 1.0, 0.0,
+        )
+    r = drag.rec[-1]
+    return r["pos"], r["rot"], motion.detach().reshape(88), disp.detach().reshape(3)
+
+
+def draw_recipe(B, mixed):
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    Zs = torch.randn(B, 24, generator=g) * 0.3
+    Z0 = torch.randn(B, 24, generator=g) * 0.3
+    ZT = Z0 + 0.05 * torch.randn(B, 24, generator=g)
+    CR = torch.randn(B, 4, generator=g)
+    CR = CR / torch.linalg.norm(CR, dim=-1, keepdim=True)
+    tracked = None
+    if mixed:
+        Eb = torch.randint(1, 7, (B,), generator=g)
+        tracked = []
+        for b in range(B):
+            perm = torch.randperm(6, generator=g)
+            tracked.append(sorted(TRACK6[int(i)] for i in perm[: int(Eb[b])]))
+    return Zs, Z0, ZT, CR, tracked
+
+
+def run_recipe(name, B, track, cfg_weights, lam_tmp, n_iter, offsets_t, parents,
+               mixed=False, weight_rounding=None, early_stop=False):
+    gm, td, drag, stub = build_reference(parents, weight_rounding)
+    Zs, Z0, ZT, CR, tracked = draw_recipe(B, mixed)
+    out = dict(
+        z0=Z0.numpy(), z_tgt=ZT.numpy(), cur_rot=CR.numpy(), z_src=Zs.numpy(),
+        w=np.zeros((B, NJ, 2), np.float32), tracked=np.zeros((B, NJ), np.uint8),
+        tgt_pos=np.zeros((B, NJ, 3), np.float32), tgt_rot=np.zeros((B, NJ, 9), np.float32),
+        z_final=np.zeros((B, 24), np.float32), z_pre=np.zeros((B, 24), np.float32),
+        pose=np.zeros((B, 88), np.float32), pose_ret=np.zeros((B, 88), np.float32),
+        disp_norm=np.zeros((B, 3), np.float32),
+        world_disp=np.zeros((B, 3), np.float32), world_rot=np.zeros((B, 4), np.float32),
+        pos=np.zeros((B, NJ, 3), np.float32), rot=np.zeros((B, NJ, 9), np.float32),
+        global_pos_ret=np.zeros((B, 3), np.float32),
+        loss_hist=np.full((B, n_iter, 3), np.nan, np.float32), iters=np.zeros((B,), np.int32),
+    )
+    for b in range(B):
+        tr = tracked[b] if mixed else track
+        idx = torch.tensor(tr, dtype=torch.int64)
+        wj = cfg_weights[idx]
+        pos_t, rot_t, _, _ = forward_fk(drag, td, Zs[b], CR[b], offsets_t)
+        tp, tR = pos_t[idx].clone(), rot_t[idx].clone()
+        out["w"][b, tr] = wj.numpy()
+        out["tracked"][b, tr] = 1
+        out["tgt_pos"][b, tr] = tp.numpy()
+        out["tgt_rot"][b, tr] = tR.reshape(-1, 9).numpy()
+
+        reset_state(drag, Z0[b], CR[b])
+        stub.z_tgt = ZT[b]
+        captured = {}
+        orig_decoder_forward = drag.decoder.forward
+
+        def rec_forward(*a, **k):
+            m, d = orig_decoder_forward(*a, **k)
+            captured["motion"], captured["disp"] = m.detach().clone(), d.detach().clone()
+            return m, d
+
+        drag.decoder.forward = rec_forward
+        if early_stop:  # the reference's own eval settings, eval_drag.py:210-214
+            kw = dict(stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=n_iter, min_loss_incr=0.00001)
+        else:
+            kw = dict(stop_eps_pos=0.0, stop_eps_rot=0.0, max_iter=n_iter, min_loss_incr=-float("inf"))
+        pose_ret, gpos_ret = drag.run(
+            target_ee_pos=tp, target_ee_rot=tR, mask_joints=idx, weights_joints=wj,
+            offsets=offsets_t, learning_rate=1e-2, lambda_rot=1, lambda_temporal=lam_tmp,
+            temporal_future_window=0, height_indices=[0, 4, 8, 13, 17, 21],
+            joint_adjustment_indices=None, joint_adjustment_weight=0.0, verbose=False, **kw
+        )
+        drag.decoder.forward = orig_decoder_forward
+        it = len(drag.rec)
+        last = drag.rec[-1]
+        out["iters"][b] = it
+        out["z_final"][b] = drag.latent.detach().reshape(24).numpy()
+        out["z_pre"][b] = drag.current_latent.reshape(24).numpy()
+        out["pose"][b] = captured["motion"].reshape(88).numpy()
+        out["disp_norm"][b] = captured["disp"].reshape(3).numpy()
+        out["pose_ret"][b] = pose_ret.detach().reshape(88).numpy()
+        out["global_pos_ret"][b] = gpos_ret.detach().reshape(3).numpy()
+        out["world_disp"][b] = last["world_disp"].numpy()
+        out["world_rot"][b] = last["world_rot"].numpy()
+        out["pos"][b] = last["pos"].numpy()
+        out["rot"][b] = last["rot"].reshape(NJ, 9).numpy()
+        for i, r in enumerate(drag.rec):
+            out["loss_hist"][b, i] = r["losses"]
+        if b % 8 == 0:
+            print(f"[{name}] frame {b}/{B} iters={it} losses={last['losses']}", flush=True)
+    meta = dict(name=name, B=B, n_iter=n_iter, lr=1e-2, lambda_rot=1.0, lambda_tmp=lam_tmp,
+                betas=[0.9, 0.999], eps=1e-8, mixed=mixed, weight_rounding=weight_rounding or "none",
+                early_stop=bool(early_stop),
+                stop_eps_pos=1e-4 if early_stop else 0.0, stop_eps_rot=1e-2 if early_stop else 0.0,
+                min_loss_incr=1e-5 if early_stop else None, torch=torch.__version__)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out
+
+
+def export_model(parents, offsets):
+    sd = torch.load(os.path.join(REF, "models/model_dancedb/generator.pt"), map_location="cpu")["model_state_dict"]
+    data = torch.load(os.path.join(REF, "models/model_dancedb/data.pt"), map_location="cpu")
+    arrs = {k.replace("autoencoder.", ""): v.numpy() for k, v in sd.items()}
+    arrs["means.dqs"] = data["means"]["dqs"].numpy()
+    arrs["means.displacement"] = data["means"]["displacement"].numpy()
+    arrs["stds.dqs"] = data["stds"]["dqs"].numpy()
+    arrs["stds.displacement"] = data["stds"]["displacement"].numpy()
+    arrs["parents"] = parents
+    arrs["offsets"] = offsets
+    path = os.path.join(REPO, "dragposer_amd", "data", "model_dancedb.npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def anchors(parents, offsets_t):
+    """Known-answer anchors A1/A2 of SURVEY.md section 8.1 -> tests/golden/anchors.npz."""
+    gm, td, drag, stub = build_reference(parents)
+    pos, rot, motion, disp = forward_fk(drag, td, torch.zeros(24), torch.tensor([1.0, 0, 0, 0]), offsets_t)
+    a1 = dict(motion=motion.numpy(), disp_norm=disp.numpy(), pos=pos.numpy(), rot=rot.reshape(NJ, 9).numpy(),
+              world_disp=drag.rec[-1]["world_disp"].numpy())
+    # A2: z=0, all targets 0 / I, z_tgt = 0.1, weights of the 6-tracker config, one Adam step
+    reset_state(drag, torch.zeros(24), torch.tensor([1.0, 0, 0, 0]))
+    stub.z_tgt = torch.full((24,), 0.1)
+    idx = torch.tensor(TRACK6)
+    wj = torch.tensor([[10.0, 10.0]] + [[5.0, 0.01]] * 5)
+    motion, disp = drag.decoder(drag.latent, td.mean_dqs, td.std_dqs)
+    lo = drag.loss(motion, disp, torch.zeros(1, 1, 6, 3), torch.eye(3).expand(1, 1, 6, 3, 3), stub.z_tgt,
+                   offsets_t, idx, wj, 1.0, 0.02)
+    (lo[0] + lo[1] + lo[2]).backward()
+    a2 = dict(losses=np.array([float(lo[0]), float(lo[1]), float(lo[2])], np.float64),
+              grad=drag.latent.grad.reshape(24).numpy().copy())
+    reset_state(drag, torch.zeros(24), torch.tensor([1.0, 0, 0, 0]))
+    drag.run(target_ee_pos=torch.zeros(6, 3), target_ee_rot=torch.eye(3).expand(6, 3, 3).clone(),
+             mask_joints=idx, weights_joints=wj, offsets=offsets_t, stop_eps_pos=0.0, stop_eps_rot=0.0,
+             max_iter=1, min_loss_incr=-float("inf"), learning_rate=1e-2, lambda_rot=1, lambda_temporal=0.02,
+             temporal_future_window=0, joint_adjustment_indices=None)
+    a2["z_after_one_step"] = drag.latent.detach().reshape(24).numpy().copy()
+    path = os.path.join(REPO, "tests", "golden", "anchors.npz")
+    np.savez_compressed(path, **{f"a1_{k}": v for k, v in a1.items()}, **{f"a2_{k}": v for k, v in a2.items()})
+    print("wrote", path)
+    print("A1 motion[:8]", a1["motion"][:8], "\nA2 losses", a2["losses"], "\nA2 grad[:4]", a2["grad"][:4])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es")
+    ap.add_argument("--frames", type=int, default=64)
+    args = ap.parse_args()
+    todo = args.only.split(",")
+    parents, offsets = parse_bvh_skeleton(os.path.join(REF, "data/example/eval/example.bvh"))
+    assert list(parents) == [0, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 12, 11, 14, 15, 16, 11, 18, 19, 20]
+    offsets_t = torch.tensor(offsets)
+    gold = os.path.join(REPO, "tests", "golden")
+    os.makedirs(gold, exist_ok=True)
+    with open(os.path.join(REF, "config/6_trackers_config.json")) as f:
+        cfg6 = json.load(f)
+    with open(os.path.join(REF, "config/3_trackers_config.json")) as f:
+        cfg3 = json.load(f)
+    w6, w3 = torch.tensor(cfg6["weights"], dtype=torch.float32), torch.tensor(cfg3["weights"], dtype=torch.float32)
+    B = args.frames
+    if "model" in todo:
+        export_model(parents, offsets)
+    if "anchors" in todo:
+        anchors(parents, offsets_t)
+    jobs = {
+        "s1": dict(track=TRACK6, cfg_weights=w6, lam_tmp=cfg6["lambda_temporal"], n_iter=50),
+        "s3": dict(track=TRACK3, cfg_weights=w3, lam_tmp=cfg3["lambda_temporal"], n_iter=100),
+        "s4": dict(track=TRACK6, cfg_weights=w6, lam_tmp=cfg6["lambda_temporal"], n_iter=50, mixed=True,
+                   weight_rounding="bf16"),
+        "es": dict(track=TRACK6, cfg_weights=w6, lam_tmp=cfg6["lambda_temporal"], n_iter=100, early_stop=True),
+    }
+    for name, kw in jobs.items():
+        if name in todo:
+            out = run_recipe(name, B, offsets_t=offsets_t, parents=parents, **kw)
+            path = os.path.join(gold, f"{name}.npz")
+            np.savez_compressed(path, **out)
+            print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
+if __name__ == "__main__":
+    main()
