@@ -1,0 +1,113 @@
+"""ctypes binding of libdragposer_hip.so (the C ABI declared in include/dragposer.h).
+
+There is no fallback: if the shared library is missing or cannot be loaded this module raises,
+and every product entry point built on it fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdragposer_hip.so")
+
+DP_OK = 0
+DP_ERR_INVALID = -1
+DP_ERR_DEVICE = -2
+DP_ERR_UNSUPPORTED = -3
+DP_ERR_LAUNCH = -4
+DP_WEIGHTS_FP32 = 0
+DP_WEIGHTS_BF16 = 1
+DP_MAX_ITERS = 256
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+_u8 = C.POINTER(C.c_ubyte)
+
+
+class DpModel(C.Structure):
+    _fields_ = [
+        ("f_latent_w", _f), ("f_latent_b", _f),
+        ("unpool_w", _f * 3), ("conv_w", _f * 3), ("conv_mask", _f * 3), ("conv_b", _f * 3),
+        ("mean_q", _f), ("std_q", _f), ("mean_disp", _f), ("std_disp", _f),
+        ("parents", _i), ("offsets", _f), ("weight_dtype", C.c_int),
+    ]
+
+
+class DpFolded(C.Structure):
+    _fields_ = [
+        ("A0", C.c_float * (40 * 24)), ("c0", C.c_float * 40),
+        ("A1", C.c_float * (60 * 40)), ("b1", C.c_float * 60),
+        ("A2", C.c_float * (92 * 60)), ("b2", C.c_float * 92),
+    ]
+
+
+class DpBatch(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_int),
+        ("z0", C.c_void_p), ("z_tgt", C.c_void_p), ("cur_rot", C.c_void_p), ("tgt_pos", C.c_void_p),
+        ("tgt_rot", C.c_void_p), ("w", C.c_void_p), ("tracked", C.c_void_p),
+    ]
+
+
+class DpParams(C.Structure):
+    _fields_ = [
+        ("n_iter", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("lambda_rot", C.c_float), ("lambda_tmp", C.c_float), ("early_stop", C.c_int),
+        ("stop_eps_pos", C.c_float), ("stop_eps_rot", C.c_float), ("min_loss_incr", C.c_float),
+    ]
+
+
+class DpResult(C.Structure):
+    _fields_ = [
+        ("z", C.c_void_p), ("z_pre", C.c_void_p), ("pose", C.c_void_p), ("disp", C.c_void_p),
+        ("world_disp", C.c_void_p), ("world_rot", C.c_void_p), ("pos", C.c_void_p), ("rot", C.c_void_p),
+        ("loss", C.c_void_p), ("iters", C.c_void_p),
+    ]
+
+
+# every symbol include/dragposer.h declares (checked by tests/test_abi.py)
+PUBLIC_SYMBOLS = (
+    "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
+    "dp_forward", "dp_kernel_geometry",
+)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError with the build hint when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  dragposer_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.dp_version.restype = C.c_int
+    lib.dp_last_error.restype = C.c_char_p
+    lib.dp_last_error.argtypes = [C.c_void_p]
+    lib.dp_fold_decoder.argtypes = [C.POINTER(DpModel), C.POINTER(DpFolded)]
+    lib.dp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(DpModel), C.c_int]
+    lib.dp_destroy.argtypes = [C.c_void_p]
+    lib.dp_optimize.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult), C.c_void_p]
+    lib.dp_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DpResult), C.c_void_p]
+    lib.dp_kernel_geometry.argtypes = [C.c_void_p, _i, _i, _i]
+    # private test hooks (not part of include/dragposer.h)
+    lib.dp_optimize_debug.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult),
+                                      C.c_void_p, C.c_void_p]
+    lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f]
+    lib.dp_debug_items.argtypes = [C.POINTER(DpModel), C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def last_error(ctx=None):
+    msg = load().dp_last_error(ctx)
+    return msg.decode() if msg else ""
+
+
+class DragPoserError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dragposer error {code}: {msg}")
+        self.code = code

@@ -1,0 +1,405 @@
+// dp_host.cpp -- host side of libdragposer_hip.so: decoder folding, MFMA fragment packing,
+// skeleton tables, context management and the C ABI declared in include/dragposer.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dragposer.h"
+#include "dp_kernel.h"
+
+using namespace dpl;
+
+struct dp_ctx {
+    int device = -1;
+    float* d_wfrag = nullptr;
+    float* d_bias = nullptr;
+    ItemConst* d_items = nullptr;
+    dp_folded folded;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(dp_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+
+extern "C" int dp_version(void) { return DP_VERSION; }
+
+extern "C" const char* dp_last_error(const dp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+static float round_bf16(float x)
+{ // nearest-even; NaN/Inf do not occur in checkpoint weights
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    std::memcpy(&x, &u, 4);
+    return x;
+}
+
+static bool model_ptrs_ok(const dp_model* m)
+{
+    if (!m || !m->f_latent_w || !m->f_latent_b || !m->mean_q || !m->std_q || !m->mean_disp || !m->std_disp ||
+        !m->parents || !m->offsets)
+        return false;
+    for (int l = 0; l < 3; ++l)
+        if (!m->unpool_w[l] || !m->conv_w[l] || !m->conv_mask[l] || !m->conv_b[l]) return false;
+    return true;
+}
+
+// A0 = (W0*M0) U0 Wf, c0 = (W0*M0) U0 bf + b0, A1 = (W1*M1) U1, A2 = (W2*M2) U2
+// (reference: autoencoder.py:228-234, skeleton.py:120,245 -- no non-linearity between these steps)
+extern "C" int dp_fold_decoder(const dp_model* m, dp_folded* out)
+{
+    if (!model_ptrs_ok(m) || !out) return fail(nullptr, DP_ERR_INVALID, "dp_fold_decoder: NULL pointer in model");
+    const int dims[4] = {24, 40, 60, 92};
+    const bool bf = m->weight_dtype == DP_WEIGHTS_BF16;
+    if (m->weight_dtype != DP_WEIGHTS_FP32 && !bf) return fail(nullptr, DP_ERR_INVALID, "dp_fold_decoder: unknown weight_dtype");
+    auto wq = [&](float x) { return bf ? round_bf16(x) : x; };
+    // T = U0 Wf (40x24), tb = U0 bf
+    std::vector<double> T(40 * 24), tb(40);
+    for (int i = 0; i < 40; ++i) {
+        for (int k = 0; k < 24; ++k) {
+            double s = 0;
+            for (int j = 0; j < 24; ++j) s += (double)m->unpool_w[0][i * 24 + j] * (double)wq(m->f_latent_w[j * 24 + k]);
+            T[i * 24 + k] = s;
+        }
+        double s = 0;
+        for (int j = 0; j < 24; ++j) s += (double)m->unpool_w[0][i * 24 + j] * (double)m->f_latent_b[j];
+        tb[i] = s;
+    }
+    auto wm = [&](int l, int i, int j) { return (double)(wq(m->conv_w[l][i * dims[l + 1] + j]) * m->conv_mask[l][i * dims[l + 1] + j]); };
+    for (int i = 0; i < 40; ++i) {
+        for (int k = 0; k < 24; ++k) {
+            double s = 0;
+            for (int j = 0; j < 40; ++j) s += wm(0, i, j) * T[j * 24 + k];
+            out->A0[i * 24 + k] = (float)s;
+        }
+        double s = m->conv_b[0][i];
+        for (int j = 0; j < 40; ++j) s += wm(0, i, j) * tb[j];
+        out->c0[i] = (float)s;
+    }
+    for (int i = 0; i < 60; ++i) {
+        for (int k = 0; k < 40; ++k) {
+            double s = 0;
+            for (int j = 0; j < 60; ++j) s += wm(1, i, j) * (double)m->unpool_w[1][j * 40 + k];
+            out->A1[i * 40 + k] = (float)s;
+        }
+        out->b1[i] = m->conv_b[1][i];
+    }
+    for (int i = 0; i < 92; ++i) {
+        for (int k = 0; k < 60; ++k) {
+            double s = 0;
+            for (int j = 0; j < 92; ++j) s += wm(2, i, j) * (double)m->unpool_w[2][j * 60 + k];
+            out->A2[i * 60 + k] = (float)s;
+        }
+        out->b2[i] = m->conv_b[2][i];
+    }
+    return DP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skeleton-derived layout of the P3 items (see dp_layout.h)
+struct ItemPlan {
+    int nvirt = 0;
+    int virt_parent[MAX_VIRT] = {0, 0, 0}; // joint whose quad virtual item v copies
+    int virt_child[MAX_VIRT] = {0, 0, 0};  // the extra child bone it handles
+    int first_child[NJ];                   // child handled by the joint's own item (-1: leaf)
+    int root_child[MAX_ROOT_CH] = {-1, -1, -1};
+};
+
+static int plan_items(const int* par, ItemPlan& pl, std::string& err)
+{
+    if (par[0] != 0) { err = "parents[0] must be 0"; return DP_ERR_INVALID; }
+    for (int j = 1; j < NJ; ++j)
+        if (par[j] < 0 || par[j] >= j) { err = "parents must be topologically ordered (parents[j] < j)"; return DP_ERR_INVALID; }
+    for (int j = 0; j < NJ; ++j) pl.first_child[j] = -1;
+    int nroot = 0;
+    for (int k = 1; k < NJ; ++k) {
+        const int p = par[k];
+        if (p == 0) {
+            if (nroot == MAX_ROOT_CH) { err = "root has more than 3 children"; return DP_ERR_UNSUPPORTED; }
+            pl.root_child[nroot++] = k;
+        } else if (pl.first_child[p] < 0) {
+            pl.first_child[p] = k;
+        } else {
+            if (pl.nvirt == MAX_VIRT) { err = "more than 3 extra child bones on non-root joints"; return DP_ERR_UNSUPPORTED; }
+            pl.virt_parent[pl.nvirt] = p;
+            pl.virt_child[pl.nvirt] = k;
+            ++pl.nvirt;
+        }
+    }
+    return DP_OK;
+}
+
+// weight of product g at (output row, input column); zero outside the real matrix
+static float gemm_w(const dp_folded& f, const ItemPlan& pl, int g, int row, int col)
+{
+    if (row >= G_ROWS[g]) return 0.f;
+    if (g == G_L2 && col == L2_ONE_COL) return f.b2[row]; // bias rides on the constant-1 column
+    if (g == G_B2 && col >= 4 * ITEM_VIRT0) {             // duplicated rows for the virtual quads
+        const int v = (col - 4 * ITEM_VIRT0) / 4;
+        if (v >= pl.nvirt) return 0.f;
+        return f.A2[(4 * pl.virt_parent[v] + (col & 3)) * 60 + row];
+    }
+    if (col >= G_KREAL[g]) return 0.f;
+    switch (g) {
+    case G_L0: return f.A0[row * 24 + col];
+    case G_L1: return f.A1[row * 40 + col];
+    case G_L2: return f.A2[row * 60 + col];
+    case G_B2: return (col == 91) ? 0.f : f.A2[col * 60 + row]; // A2^T; channel 91 is unused padding
+    case G_B1: return f.A1[col * 40 + row]; // A1^T
+    case G_B0: return f.A0[col * 24 + row]; // A0^T
+    }
+    return 0.f;
+}
+
+static float gemm_bias(const dp_folded& f, int g, int row)
+{
+    if (row >= G_ROWS[g]) return 0.f;
+    switch (g) {
+    case G_L0: return f.c0[row];
+    case G_L1: return f.b1[row];
+    }
+    return 0.f;
+}
+
+// host-only, exported for the CPU tests: per-wave/per-lane MFMA operand images
+//   wfrag [NWAVE][W_REGS][64], bias [2][64] (rows of c0 / b1, zero padded)
+extern "C" int dp_debug_pack(const dp_folded* f, const int* parents, float* wfrag, float* bias)
+{
+    if (!f || !parents || !wfrag || !bias) return DP_ERR_INVALID;
+    ItemPlan pl;
+    std::string err;
+    int rc = plan_items(parents, pl, err);
+    if (rc != DP_OK) return fail(nullptr, rc, err);
+    std::memset(wfrag, 0, sizeof(float) * NWAVE * W_REGS * 64);
+    for (int r = 0; r < 64; ++r) { bias[r] = gemm_bias(*f, G_L0, r); bias[64 + r] = gemm_bias(*f, G_L1, r); }
+    const int woff[NGEMM] = {W_OFF_L0, W_OFF_L1, W_OFF_L2A, W_OFF_B2, W_OFF_B1, W_OFF_B0};
+    for (int w = 0; w < NWAVE; ++w) {
+        for (int g = 0; g < NGEMM; ++g) {
+            for (int slot = 0; slot < 2; ++slot) {
+                int half = 0;
+                const int tile = chunk_tile(g, w, slot, &half);
+                if (tile < 0) continue;
+                const int base = (slot == 0) ? woff[g] : W_OFF_L2B;
+                const int s0 = half ? G_HALF0[g] : 0, s1 = half ? G_NM[g] : G_HALF0[g];
+                for (int step = s0; step < s1; ++step) {
+                    for (int l = 0; l < 64; ++l) {
+                        const int row = 16 * tile + (l & 15), col = kcol(G_K[g], step, l >> 4);
+                        wfrag[(w * W_REGS + base + (step - s0)) * 64 + l] = gemm_w(*f, pl, g, row, col);
+                    }
+                }
+            }
+        }
+    }
+    return DP_OK;
+}
+
+// host-only, exported for the CPU tests: P3 per-item constants [32]
+extern "C" int dp_debug_items(const dp_model* m, void* out_items /* 32 x 128 B */)
+{
+    if (!model_ptrs_ok(m) || !out_items) return fail(nullptr, DP_ERR_INVALID, "dp_debug_items: NULL pointer");
+    ItemConst* it = (ItemConst*)out_items;
+    std::memset(it, 0, sizeof(ItemConst) * 32);
+    const int* par = m->parents;
+    ItemPlan pl;
+    std::string err;
+    int rc = plan_items(par, pl, err);
+    if (rc != DP_OK) return fail(nullptr, rc, err);
+    unsigned sub[NJ]; // subtree masks
+    for (int j = 0; j < NJ; ++j) sub[j] = 1u << j;
+    for (int j = NJ - 1; j >= 1; --j) sub[par[j]] |= sub[j];
+    auto set_child = [&](ItemConst& c, int k) {
+        c.ch_id = k;
+        c.ch_sub = sub[k];
+        for (int a = 0; a < 3; ++a) c.ch_off[a] = m->offsets[3 * k + a];
+    };
+    for (int id = 0; id < 32; ++id) {
+        ItemConst& c = it[id];
+        c.kind = KIND_IDLE;
+        c.ch_id = SLOT_TRASH + (id & 7);
+        c.init_id = SLOT_TRASH + (id & 7);
+        c.src_quad = ITEM_VIRT0; // a quad layer 2 always writes as zeros (channels 92..95)
+        c.dst_quad = (id < NQUAD_GY) ? id : -1;
+        unsigned long long path = 0;
+        for (int i = 0; i < MAX_PATH; ++i) path |= (unsigned long long)SLOT_ZERO << (5 * i);
+        if (id < NJ) {
+            c.kind = id == 0 ? KIND_ROOT : KIND_JOINT;
+            c.src_quad = id;
+            for (int k = 0; k < 4; ++k) { c.sd[k] = m->std_q[4 * id + k]; c.mu[k] = m->mean_q[4 * id + k]; }
+            if (id > 0 && pl.first_child[id] >= 0) set_child(c, pl.first_child[id]);
+            int chain[NJ], n = 0; // bones on the path root -> id (joint ids, root excluded)
+            for (int k = id; k != 0; k = par[k]) chain[n++] = k;
+            if (n > MAX_PATH) return fail(nullptr, DP_ERR_UNSUPPORTED, "kinematic chain deeper than 7 bones");
+            path = 0;
+            for (int i = 0; i < MAX_PATH; ++i) path |= (unsigned long long)(i < n ? chain[i] : SLOT_ZERO) << (5 * i);
+        } else if (id == ITEM_DISP) {
+            c.kind = KIND_DISP;
+            c.src_quad = ITEM_DISP;
+            for (int k = 0; k < 3; ++k) { c.sd[k] = m->std_disp[k]; c.mu[k] = m->mean_disp[k]; }
+            c.ch_sub = (1u << NJ) - 1u; // the displacement's "subtree" is every joint
+        } else if (id - ITEM_VIRT0 < pl.nvirt) {
+            const int v = id - ITEM_VIRT0, j = pl.virt_parent[v];
+            c.kind = KIND_VIRT;
+            c.src_quad = j;
+            for (int k = 0; k < 4; ++k) { c.sd[k] = m->std_q[4 * j + k]; c.mu[k] = m->mean_q[4 * j + k]; }
+            set_child(c, pl.virt_child[v]);
+        }
+        if (id < MAX_ROOT_CH && pl.root_child[id] >= 0) {
+            c.init_id = pl.root_child[id];
+            for (int a = 0; a < 3; ++a) c.init_off[a] = m->offsets[3 * pl.root_child[id] + a];
+        }
+        c.path_lo = (unsigned)(path & 0x3FFFFFFFull);
+        c.path_hi = (unsigned)(path >> 30);
+    }
+    return DP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, DP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
+{
+    if (!out) return fail(nullptr, DP_ERR_INVALID, "dp_create: out is NULL");
+    *out = nullptr;
+    if (!model_ptrs_ok(model)) return fail(nullptr, DP_ERR_INVALID, "dp_create: NULL pointer in model");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DP_ERR_DEVICE, "dp_create: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, DP_ERR_INVALID, "dp_create: bad device index");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, DP_ERR_DEVICE, std::string("dp_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    dp_ctx* ctx = new dp_ctx();
+    ctx->device = device;
+    int rc = dp_fold_decoder(model, &ctx->folded);
+    std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
+    std::vector<ItemConst> items(32);
+    if (rc == DP_OK) rc = dp_debug_pack(&ctx->folded, model->parents, wfrag.data(), bfrag.data());
+    if (rc == DP_OK) rc = dp_debug_items(model, items.data());
+    if (rc != DP_OK) { delete ctx; return rc; }
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_wfrag, wfrag.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_bias, bfrag.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_items, items.size() * sizeof(ItemConst));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_wfrag, wfrag.data(), wfrag.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_bias, bfrag.data(), bfrag.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_items, items.data(), items.size() * sizeof(ItemConst), hipMemcpyHostToDevice);
+    hipSetDevice(prev);
+    if (e != hipSuccess) {
+        std::string msg = std::string("dp_create: ") + hipGetErrorString(e);
+        hipFree(ctx->d_wfrag); hipFree(ctx->d_bias); hipFree(ctx->d_items);
+        delete ctx;
+        return fail(nullptr, DP_ERR_DEVICE, msg);
+    }
+    *out = ctx;
+    return DP_OK;
+}
+
+extern "C" int dp_destroy(dp_ctx* ctx)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    hipFree(ctx->d_wfrag);
+    hipFree(ctx->d_bias);
+    hipFree(ctx->d_items);
+    delete ctx;
+    return DP_OK;
+}
+
+extern "C" int dp_kernel_geometry(const dp_ctx*, int* frames_per_block, int* threads_per_block, int* lds_bytes)
+{
+    if (frames_per_block) *frames_per_block = FPB;
+    if (threads_per_block) *threads_per_block = NTHREADS;
+    if (lds_bytes) *lds_bytes = dp_kernel_lds_bytes();
+    return DP_OK;
+}
+
+static void fill_model_args(const dp_ctx* ctx, KArgs& k)
+{
+    std::memset(&k, 0, sizeof(k));
+    k.wfrag = ctx->d_wfrag;
+    k.bias = ctx->d_bias;
+    k.items = ctx->d_items;
+}
+
+static void fill_results(const dp_result* out, KArgs& k)
+{
+    if (!out) return;
+    k.z = out->z; k.z_pre = out->z_pre; k.pose = out->pose; k.disp = out->disp; k.world_disp = out->world_disp;
+    k.world_rot = out->world_rot; k.pos = out->pos; k.rot = out->rot; k.loss = out->loss; k.iters = out->iters;
+}
+
+static int launch(dp_ctx* ctx, KArgs& k, void* stream)
+{
+    hipError_t e = dp_launch_optimize(&k, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
+    return DP_OK;
+}
+
+// private extension used by the tests: same as dp_optimize, plus an optional debug dump
+// [B][240] = y(104) | dL/dy(104) | dL/dz(24) | pad, all of iteration 0.
+extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, float* dbg, void* stream)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    if (!in || !p) return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL batch/params");
+    if (in->n_frames <= 0) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_frames must be positive");
+    if (!in->z0 || !in->z_tgt || !in->cur_rot || !in->tgt_pos || !in->tgt_rot || !in->w || !in->tracked)
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL input array");
+    if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1,256]");
+    if (p->early_stop) return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: early_stop is not implemented in this build");
+    if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize: bad Adam hyper-parameters");
+    KArgs k;
+    fill_model_args(ctx, k);
+    k.z0 = in->z0; k.z_tgt = in->z_tgt; k.cur_rot = in->cur_rot; k.tgt_pos = in->tgt_pos; k.tgt_rot = in->tgt_rot;
+    k.w = in->w; k.tracked = in->tracked;
+    fill_results(out, k);
+    k.dbg = dbg;
+    k.n_frames = in->n_frames; k.n_iter = p->n_iter; k.mode = 0;
+    k.lam_rot = p->lambda_rot; k.lam_tmp = p->lambda_tmp; k.ctmp = 2.f * p->lambda_tmp / 24.f;
+    // torch passes (1-beta) as Python doubles into fp32 tensor ops
+    k.beta2 = p->beta2; k.one_m_b1 = (float)(1.0 - (double)p->beta1); k.one_m_b2 = (float)(1.0 - (double)p->beta2);
+    k.eps = p->eps;
+    double b1t = 1.0, b2t = 1.0;
+    for (int t = 0; t < p->n_iter; ++t) {
+        b1t *= (double)p->beta1;
+        b2t *= (double)p->beta2;
+        k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
+        k.tab.bc2s[t] = (float)std::sqrt(1.0 - b2t);
+    }
+    return launch(ctx, k, stream);
+}
+
+extern "C" int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, void* stream)
+{
+    return dp_optimize_debug(ctx, in, p, out, nullptr, stream);
+}
+
+extern "C" int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float* cur_rot, const dp_result* out, void* stream)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    if (n_frames <= 0 || !z || !cur_rot || !out) return fail(ctx, DP_ERR_INVALID, "dp_forward: bad arguments");
+    KArgs k;
+    fill_model_args(ctx, k);
+    k.z0 = z; k.cur_rot = cur_rot;
+    fill_results(out, k);
+    k.z = nullptr; k.z_pre = nullptr; k.loss = nullptr; k.iters = nullptr;
+    k.n_frames = n_frames; k.n_iter = 1; k.mode = 1;
+    return launch(ctx, k, stream);
+}

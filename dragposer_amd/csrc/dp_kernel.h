@@ -1,0 +1,36 @@
+// dp_kernel.h -- argument block shared by the host side (dp_host.cpp) and the kernel (dp_kernel.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dp_layout.h"
+
+struct AdamTab { // per-iteration scalars torch's single-tensor Adam computes in Python doubles
+    float step[dpl::MAX_ITERS]; // lr / (1 - beta1^t)
+    float bc2s[dpl::MAX_ITERS]; // sqrt(1 - beta2^t)
+};
+
+// debug dump (iteration 0 only), floats per frame
+constexpr int DBG_Y = 0;     // [104] decoder output quads (sum of the two K-half planes)
+constexpr int DBG_GY = 104;  // [104] dL/dy quads (23.. = virtual items)
+constexpr int DBG_GZ = 208;  // [24] dL/dz (incl. temporal term)
+constexpr int DBG_STRIDE = 240;
+
+struct KArgs {
+    // model (device)
+    const float* wfrag;          // [NWAVE][W_REGS][64]
+    const float* bias;           // [2][64] padded bias rows of L0 (c0) and L1 (b1)
+    const dpl::ItemConst* items; // [32]
+    // batch (device)
+    const float *z0, *z_tgt, *cur_rot, *tgt_pos, *tgt_rot, *w;
+    const unsigned char* tracked;
+    // results (device, nullable)
+    float *z, *z_pre, *pose, *disp, *world_disp, *world_rot, *pos, *rot, *loss;
+    int* iters;
+    float* dbg;
+    int n_frames, n_iter, mode; // mode 0: optimise, 1: forward only (n_iter = 1)
+    float lam_rot, lam_tmp, ctmp; // ctmp = 2 lam_tmp / 24
+    float beta2, one_m_b1, one_m_b2, eps;
+    AdamTab tab;
+};
+
+extern "C" hipError_t dp_launch_optimize(const KArgs* args, hipStream_t stream);
+extern "C" int dp_kernel_lds_bytes(void);

@@ -1,0 +1,586 @@
+// dp_kernel.hip -- the fused latent-optimisation kernel for gfx950 (MI355X).
+//
+// One launch runs ALL iterations of decode -> FK -> loss -> backward -> Adam for every frame of
+// the batch (reference: DragPose.run's while loop, python/src/drag_pose.py:296-355).
+//
+// Geometry: workgroup = 512 threads (8 waves) = 16 frames; grid = ceil(B/16).
+//   * Decoder forward/backward: six products per iteration on v_mfma_f32_16x16x4_f32, weights
+//     (A operand) resident in VGPRs for the whole kernel, activations (B operand) exchanged
+//     through LDS.  Every 16-row output tile is split in two K-halves computed by two waves that
+//     share a SIMD (two independent accumulator chains per matrix pipe); the two partial planes
+//     are summed by the consumer together with the LeakyReLU / its derivative.
+//   * Kinematics phase (P3): wave w owns frames 2w,2w+1, 32 lanes per frame, one lane per joint
+//     (+1 for the root displacement); cross-joint traffic (bones, tracker gradients) goes through
+//     wave-private LDS rows, so P3 needs no workgroup barrier inside.
+//   * Adam runs redundantly in every wave on the lanes that hold z as the B operand of layer 0.
+// 7 workgroup barriers per iteration, no global memory traffic inside the loop.
+#include <hip/hip_runtime.h>
+#include "dp_kernel.h"
+
+using namespace dpl;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------
+// LDS map (floats)
+constexpr int L_A0 = 0;                            // a0p[2][16][S_A0]   (aliased by d0p)
+constexpr int L_A1 = L_A0 + 2 * FPB * S_A0;        // a1p[2][16][S_A1]   (aliased by d1p)
+constexpr int L_Y = L_A1 + 2 * FPB * S_A1;         // yp [2][16][S_Y]    (plane 0 aliased by gy)
+constexpr int L_ZERO0 = L_Y + 2 * FPB * S_Y;       // ---- everything from here on is zeroed at start
+constexpr int L_GZ = L_ZERO0;                      // gzp[2][16][S_GZ]
+constexpr int L_BONE = L_GZ + 2 * FPB * S_GZ;      // bone[16][32][4]
+constexpr int L_GPC = L_BONE + FPB * 32 * 4;       // gpc [16][24][4]  tracker position gradients by rank
+constexpr int L_CQ = L_GPC + FPB * 24 * 4;         // cq  [16][24][4]  tracker contributions to d/d(qw)
+constexpr int L_LP = L_CQ + FPB * 24 * 4;          // lp  [16][24][2]  tracker loss terms
+constexpr int L_QD = L_LP + FPB * 24 * 2;          // qd  [16][8]      qw[4], d[3]
+constexpr int L_ADM = L_QD + FPB * 8;              // adam m [2][16][S_AD]
+constexpr int L_ADV = L_ADM + 2 * FPB * S_AD;      // adam v [2][16][S_AD]
+constexpr int L_ZT = L_ADV + 2 * FPB * S_AD;       // z_tgt  [16][S_AD]
+constexpr int L_TRK = L_ZT + FPB * S_AD;           // TrackIn[16][24]
+constexpr int L_ITEM = L_TRK + FPB * 24 * 16;      // ItemConst[32]
+constexpr int L_BIAS = L_ITEM + 32 * 32;           // bias rows of L0 (48) and L1 (64), padded to 64 each
+constexpr int WB_STRIDE = 28;                      // backward weights per lane: bL2[14] | bL1[8] | bL0[5] | pad
+constexpr int L_WB = L_BIAS + 128;                 // wb[8 waves][64 lanes][WB_STRIDE]
+constexpr int L_TOTAL = L_WB + NWAVE * 64 * WB_STRIDE;
+static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
+
+DEV f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+DEV void wave_sync()
+{ // orders this wave's LDS writes before its later LDS reads (other lanes' data); no instruction
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+DEV float lrelu(float x) { return fmaxf(x, 0.2f * x); }
+DEV float dlrelu(float a, float g) { return a > 0.f ? g : 0.2f * g; } // torch: x > 0 ? g : g*slope
+
+struct M3 { float m00, m01, m02, m10, m11, m12, m20, m21, m22; };
+struct Q4 { float w, x, y, z; };
+struct V3 { float x, y, z; };
+
+DEV M3 quat_to_mat(Q4 q)
+{ // reference utils.py:49-74
+    float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    float xx = q.x * x2, yy = q.y * y2, zz = q.z * z2, xy = q.x * y2, xz = q.x * z2, yz = q.y * z2;
+    float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    M3 m;
+    m.m00 = 1.f - (yy + zz); m.m01 = xy - wz;         m.m02 = xz + wy;
+    m.m10 = xy + wz;         m.m11 = 1.f - (xx + zz); m.m12 = yz - wx;
+    m.m20 = xz - wy;         m.m21 = yz + wx;         m.m22 = 1.f - (xx + yy);
+    return m;
+}
+
+DEV Q4 quat_mat_grad(Q4 q, M3 X)
+{ // g_k = sum_ab dM_ab/dq_k X_ab
+    Q4 g;
+    float a = X.m21 - X.m12, b = X.m02 - X.m20, c = X.m10 - X.m01; // antisymmetric part
+    float s01 = X.m01 + X.m10, s02 = X.m02 + X.m20, s12 = X.m12 + X.m21;
+    g.w = 2.f * (q.x * a + q.y * b + q.z * c);
+    g.x = 2.f * (q.w * a + q.y * s01 + q.z * s02 - 2.f * q.x * (X.m11 + X.m22));
+    g.y = 2.f * (q.w * b + q.x * s01 + q.z * s12 - 2.f * q.y * (X.m00 + X.m22));
+    g.z = 2.f * (q.w * c + q.x * s02 + q.y * s12 - 2.f * q.z * (X.m00 + X.m11));
+    return g;
+}
+
+DEV Q4 quat_mul(Q4 a, Q4 b)
+{
+    Q4 o;
+    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    o.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    o.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return o;
+}
+
+DEV V3 mat_vec(M3 m, V3 v) { return {m.m00 * v.x + m.m01 * v.y + m.m02 * v.z, m.m10 * v.x + m.m11 * v.y + m.m12 * v.z, m.m20 * v.x + m.m21 * v.y + m.m22 * v.z}; }
+DEV V3 matT_vec(M3 m, V3 v) { return {m.m00 * v.x + m.m10 * v.y + m.m20 * v.z, m.m01 * v.x + m.m11 * v.y + m.m21 * v.z, m.m02 * v.x + m.m12 * v.y + m.m22 * v.z}; }
+
+DEV M3 matT_mat(M3 a, M3 b)
+{ // a^T b
+    M3 c;
+    c.m00 = a.m00 * b.m00 + a.m10 * b.m10 + a.m20 * b.m20; c.m01 = a.m00 * b.m01 + a.m10 * b.m11 + a.m20 * b.m21; c.m02 = a.m00 * b.m02 + a.m10 * b.m12 + a.m20 * b.m22;
+    c.m10 = a.m01 * b.m00 + a.m11 * b.m10 + a.m21 * b.m20; c.m11 = a.m01 * b.m01 + a.m11 * b.m11 + a.m21 * b.m21; c.m12 = a.m01 * b.m02 + a.m11 * b.m12 + a.m21 * b.m22;
+    c.m20 = a.m02 * b.m00 + a.m12 * b.m10 + a.m22 * b.m20; c.m21 = a.m02 * b.m01 + a.m12 * b.m11 + a.m22 * b.m21; c.m22 = a.m02 * b.m02 + a.m12 * b.m12 + a.m22 * b.m22;
+    return c;
+}
+
+DEV M3 mat_mat(M3 a, M3 b)
+{
+    M3 c;
+    c.m00 = a.m00 * b.m00 + a.m01 * b.m10 + a.m02 * b.m20; c.m01 = a.m00 * b.m01 + a.m01 * b.m11 + a.m02 * b.m21; c.m02 = a.m00 * b.m02 + a.m01 * b.m12 + a.m02 * b.m22;
+    c.m10 = a.m10 * b.m00 + a.m11 * b.m10 + a.m12 * b.m20; c.m11 = a.m10 * b.m01 + a.m11 * b.m11 + a.m12 * b.m21; c.m12 = a.m10 * b.m02 + a.m11 * b.m12 + a.m12 * b.m22;
+    c.m20 = a.m20 * b.m00 + a.m21 * b.m10 + a.m22 * b.m20; c.m21 = a.m20 * b.m01 + a.m21 * b.m11 + a.m22 * b.m21; c.m22 = a.m20 * b.m02 + a.m21 * b.m12 + a.m22 * b.m22;
+    return c;
+}
+
+DEV M3 mat_matT(M3 a, M3 b)
+{ // a b^T
+    M3 c;
+    c.m00 = a.m00 * b.m00 + a.m01 * b.m01 + a.m02 * b.m02; c.m01 = a.m00 * b.m10 + a.m01 * b.m11 + a.m02 * b.m12; c.m02 = a.m00 * b.m20 + a.m01 * b.m21 + a.m02 * b.m22;
+    c.m10 = a.m10 * b.m00 + a.m11 * b.m01 + a.m12 * b.m02; c.m11 = a.m10 * b.m10 + a.m11 * b.m11 + a.m12 * b.m12; c.m12 = a.m10 * b.m20 + a.m11 * b.m21 + a.m12 * b.m22;
+    c.m20 = a.m20 * b.m00 + a.m21 * b.m01 + a.m22 * b.m02; c.m21 = a.m20 * b.m10 + a.m21 * b.m11 + a.m22 * b.m12; c.m22 = a.m20 * b.m20 + a.m21 * b.m21 + a.m22 * b.m22;
+    return c;
+}
+
+// B-operand loaders: row `p` (one frame) of an LDS buffer, columns in kcol order.
+template <int K> DEV void load_row(const float* p, int h, float (&b)[K / 4])
+{
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+        f4 v = *(const f4*)(p + 16 * s + 4 * h);
+        b[4 * s + 0] = v.x; b[4 * s + 1] = v.y; b[4 * s + 2] = v.z; b[4 * s + 3] = v.w;
+    }
+    if (K % 16 == 8) {
+        f2 v = *(const f2*)(p + (K / 16) * 16 + 2 * h);
+        b[(K / 16) * 4 + 0] = v.x; b[(K / 16) * 4 + 1] = v.y;
+    }
+}
+
+template <int K> DEV void load_row_sum(const float* p0, const float* p1, int h, float (&b)[K / 4])
+{
+    float b0[K / 4], b1[K / 4];
+    load_row<K>(p0, h, b0);
+    load_row<K>(p1, h, b1);
+#pragma unroll
+    for (int i = 0; i < K / 4; ++i) b[i] = b0[i] + b1[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[L_TOTAL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f16 = lane & 15, h = lane >> 4;   // MFMA roles: frame column, K / row group
+    const int pf = 2 * wave + (lane >> 5);      // P3 roles: frame (row of every LDS buffer)
+    const int it_id = lane & 31;                //           item id
+    const int blk0 = blockIdx.x * FPB;
+    const int nB = a.n_frames;
+    const bool optimise = (a.mode == 0);
+
+    float* a0p = lds + L_A0;
+    float* a1p = lds + L_A1;
+    float* yp = lds + L_Y;
+    float* gzp = lds + L_GZ;
+    float* bone = lds + L_BONE + pf * 128;
+    float* gpc = lds + L_GPC + pf * 96;
+    float* cqb = lds + L_CQ + pf * 96;
+    float* lpb = lds + L_LP + pf * 48;
+    float* qdb = lds + L_QD + pf * 8;
+    const ItemConst* icp = (const ItemConst*)(lds + L_ITEM) + it_id;
+    const TrackIn* tin = (const TrackIn*)(lds + L_TRK) + pf * 24 + (it_id < NJ ? it_id : 23);
+
+    // ---- zero the scratch part of the LDS, copy the item table
+    for (int i = tid; i < L_ITEM - L_ZERO0; i += NTHREADS) lds[L_ZERO0 + i] = 0.f;
+    for (int i = tid; i < 32 * 32; i += NTHREADS) lds[L_ITEM + i] = ((const float*)a.items)[i];
+    if (tid < 128) lds[L_BIAS + tid] = a.bias[tid];
+    __syncthreads();
+
+    // ---- loop-invariant MFMA A operands: forward weights stay in VGPRs for the whole kernel,
+    //      backward weights are parked in LDS (lane-major) and fetched ahead of each backward phase
+    float W[W_OFF_B2];
+#pragma unroll
+    for (int i = 0; i < W_OFF_B2; ++i) W[i] = a.wfrag[(wave * W_REGS + i) * 64 + lane];
+    float* wbl = lds + L_WB + (wave * 64 + lane) * WB_STRIDE;
+#pragma unroll
+    for (int i = 0; i < W_REGS - W_OFF_B2; ++i) wbl[i] = a.wfrag[(wave * W_REGS + W_OFF_B2 + i) * 64 + lane];
+
+    // ---- latent on the layer-0 B-operand lanes (every wave keeps a copy); Adam state in LDS
+    float zf[6];
+    {
+        const int gf = min(blk0 + f16, nB - 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int col = kcol(24, i, h);
+            zf[i] = a.z0[gf * LAT + col];
+            if (optimise && wave == 0) lds[L_ZT + f16 * S_AD + col] = a.z_tgt[gf * LAT + col];
+        }
+    }
+
+    // ---- P3 per-lane identity and per-frame tracker inputs
+    const int kind = icp->kind;
+    const bool is_joint = kind == KIND_JOINT || kind == KIND_ROOT; // owns a tracker slot / outputs
+    const bool has_quat = kind != KIND_DISP && kind != KIND_IDLE;
+    const bool is_root = kind == KIND_ROOT;
+    const bool is_disp = kind == KIND_DISP;
+    const int gfp = blk0 + pf;
+    const int gfc = min(gfp, nB - 1);
+    const bool fvalid = gfp < nB;
+    const Q4 cur = {a.cur_rot[gfc * 4 + 0], a.cur_rot[gfc * 4 + 1], a.cur_rot[gfc * 4 + 2], a.cur_rot[gfc * 4 + 3]};
+    bool trk = false;
+    if (optimise && is_joint) trk = a.tracked[gfc * NJ + it_id] != 0;
+    const unsigned long long bal = __ballot(trk);
+    const unsigned tmask = (lane >> 5) ? (unsigned)(bal >> 32) : (unsigned)bal; // tracked joints of my frame
+    const int E = __popc(tmask);
+    const int rank = __popc(tmask & ((1u << it_id) - 1u));
+    const int Emax = max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 32));
+    if (trk) {
+        const float invE = 1.f / (float)E;
+        const float* p = a.tgt_pos + (size_t)(gfc * NJ + it_id) * 3;
+        const float* r = a.tgt_rot + (size_t)(gfc * NJ + it_id) * 9;
+        const float wp = a.w[(gfc * NJ + it_id) * 2 + 0], wr = a.w[(gfc * NJ + it_id) * 2 + 1];
+        TrackIn t;
+        t.tp[0] = p[0]; t.tp[1] = p[1]; t.tp[2] = p[2];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.tR[i] = r[i];
+        t.clp = wp * invE * (1.f / 3.f);             // loss_pos coefficient  w_pos / (3E)
+        t.clr = a.lam_rot * wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
+        t.cgp = 2.f * t.clp;
+        t.cgr = 2.f * t.clr;
+        *(TrackIn*)(lds + L_TRK + (pf * 24 + it_id) * 16) = t;
+    }
+    // constant root-frame bones of the root's children
+    if (it_id < MAX_ROOT_CH) *(f4*)(bone + icp->init_id * 4) = f4{icp->init_off[0], icp->init_off[1], icp->init_off[2], 0.f};
+
+    float a0f[10], a1f[16];
+    __syncthreads();
+
+    for (int iter = 0; iter < a.n_iter; ++iter) {
+        const bool last = (iter == a.n_iter - 1);
+
+        // ================= L0: a0 = A0 z + c0 (24 -> 40), 3 tiles x 2 K-halves on waves 0..5
+        if (wave < 6) {
+            const int t = wave % 3, hf = wave / 3;
+            f4 acc = *(const f4*)(lds + L_BIAS + 16 * t + 4 * h);
+            if (hf) acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc = mfma4(W[W_OFF_L0 + i], hf ? zf[3 + i] : zf[i], acc);
+            *(f4*)(a0p + (hf * FPB + f16) * S_A0 + 16 * t + 4 * h) = acc;
+        }
+        __syncthreads();
+
+        // ================= L1: a1 = A1 lrelu(a0) + b1 (40 -> 60), 4 tiles x 2 halves
+        load_row_sum<40>(a0p + f16 * S_A0, a0p + (FPB + f16) * S_A0, h, a0f);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a0f[i] = lrelu(a0f[i]);
+        {
+            const int t = wave & 3, hf = wave >> 2;
+            f4 acc = *(const f4*)(lds + L_BIAS + 64 + 16 * t + 4 * h);
+            if (hf) acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc = mfma4(W[W_OFF_L1 + i], hf ? a0f[5 + i] : a0f[i], acc);
+            *(f4*)(a1p + (hf * FPB + f16) * S_A1 + 16 * t + 4 * h) = acc;
+        }
+        __syncthreads();
+
+        // ================= L2: y = A2 lrelu(a1) + b2 (60 -> 92), 6 tiles x 2 halves = 12 chunks
+        load_row_sum<64>(a1p + f16 * S_A1, a1p + (FPB + f16) * S_A1, h, a1f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a1f[i] = lrelu(a1f[i]);
+        if (h == 3) a1f[12] = 1.f; // column 60 = kcol(64, 12, 3): constant input that carries b2
+        {
+            const int t = wave % 6, hf = wave / 6;
+            f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (wave < 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc0 = mfma4(W[W_OFF_L2A + i], a1f[i], acc0);
+                    acc1 = mfma4(W[W_OFF_L2B + i], a1f[8 + i], acc1);
+                }
+                *(f4*)(yp + (FPB + f16) * S_Y + 16 * (wave + 2) + 4 * h) = acc1;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc0 = mfma4(W[W_OFF_L2A + i], hf ? a1f[8 + i] : a1f[i], acc0);
+            }
+            *(f4*)(yp + (hf * FPB + f16) * S_Y + 16 * t + 4 * h) = acc0;
+        }
+        __syncthreads();
+
+        // ================= P3: normalise, FK, loss, backward to gy   (wave-private rows)
+        {
+            const int sq = icp->src_quad, dq = icp->dst_quad;
+            const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
+            if (a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
+            const f4 sd = *(const f4*)icp->sd, mu = *(const f4*)icp->mu;
+            const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
+            const float nn = r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z;
+            const float inv = has_quat ? 1.0f / sqrtf(nn) : 0.f;
+            const Q4 q = {r.w * inv, r.x * inv, r.y * inv, r.z * inv};
+            M3 M = quat_to_mat(q);
+            if (is_root) {
+                const Q4 qw0 = quat_mul(cur, q);
+                *(f4*)(qdb) = f4{qw0.w, qw0.x, qw0.y, qw0.z};
+                M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+            }
+            if (is_disp) *(f4*)(qdb + 4) = f4{r.w, r.x, r.y, 0.f};
+            {
+                const V3 u = mat_vec(M, V3{icp->ch_off[0], icp->ch_off[1], icp->ch_off[2]});
+                *(f4*)(bone + icp->ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
+            }
+            wave_sync();
+
+            const f4 qwv = *(const f4*)(qdb);
+            const f4 dv = *(const f4*)(qdb + 4);
+            const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
+            const M3 R0 = quat_to_mat(qw);
+            V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
+            {
+                const unsigned plo = icp->path_lo, phi = icp->path_hi;
+#pragma unroll
+                for (int i = 0; i < MAX_PATH; ++i) {
+                    const unsigned k = (i < 6) ? ((plo >> (5 * i)) & 31u) : (phi & 31u);
+                    const f4 b = *(const f4*)(bone + k * 4);
+                    pr.x += b.x; pr.y += b.y; pr.z += b.z;
+                }
+            }
+            M3 gM = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (trk) { // tracker terms in the root frame
+                const f4 t0 = *(const f4*)(tin->tp);     // tp, cgp
+                const f4 t1 = *(const f4*)(tin->tR);     // tR[0..3]
+                const f4 t2 = *(const f4*)(tin->tR + 4); // tR[4..7]
+                const f4 t3 = *(const f4*)(tin->tR + 8); // tR[8], cgr, clp, clr
+                const V3 tp = {t0.x, t0.y, t0.z};
+                const M3 tR = {t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x};
+                const float cgp = t0.w, cgr = t3.y;
+                const V3 tpr = matT_vec(R0, tp);
+                const V3 e = {pr.x - tpr.x, pr.y - tpr.y, pr.z - tpr.z};
+                const V3 gp = {cgp * e.x, cgp * e.y, cgp * e.z};
+                const M3 tRr = matT_mat(R0, tR);
+                const M3 eM = {M.m00 - tRr.m00, M.m01 - tRr.m01, M.m02 - tRr.m02, M.m10 - tRr.m10, M.m11 - tRr.m11,
+                               M.m12 - tRr.m12, M.m20 - tRr.m20, M.m21 - tRr.m21, M.m22 - tRr.m22};
+                gM = {cgr * eM.m00, cgr * eM.m01, cgr * eM.m02, cgr * eM.m10, cgr * eM.m11, cgr * eM.m12,
+                      cgr * eM.m20, cgr * eM.m21, cgr * eM.m22};
+                // dL/dR0 = -(tp gp^T + tR gM^T)  ->  contribution to dL/d(qw)
+                M3 C = mat_matT(tR, gM);
+                C.m00 = -(C.m00 + tp.x * gp.x); C.m01 = -(C.m01 + tp.x * gp.y); C.m02 = -(C.m02 + tp.x * gp.z);
+                C.m10 = -(C.m10 + tp.y * gp.x); C.m11 = -(C.m11 + tp.y * gp.y); C.m12 = -(C.m12 + tp.y * gp.z);
+                C.m20 = -(C.m20 + tp.z * gp.x); C.m21 = -(C.m21 + tp.z * gp.y); C.m22 = -(C.m22 + tp.z * gp.z);
+                const Q4 gqw_t = quat_mat_grad(qw, C);
+                *(f4*)(gpc + rank * 4) = f4{gp.x, gp.y, gp.z, 0.f};
+                *(f4*)(cqb + rank * 4) = f4{gqw_t.w, gqw_t.x, gqw_t.y, gqw_t.z};
+                if (last) {
+                    const float l_p = t3.z * (e.x * e.x + e.y * e.y + e.z * e.z);
+                    const float l_r = t3.w * (eM.m00 * eM.m00 + eM.m01 * eM.m01 + eM.m02 * eM.m02 + eM.m10 * eM.m10 + eM.m11 * eM.m11 +
+                                              eM.m12 * eM.m12 + eM.m20 * eM.m20 + eM.m21 * eM.m21 + eM.m22 * eM.m22);
+                    *(f2*)(lpb + rank * 2) = f2{l_p, l_r};
+                }
+            }
+            wave_sync();
+
+            // subtree sum of the tracker gradients below my child bone
+            V3 S = {0.f, 0.f, 0.f};
+            {
+                const unsigned sub = icp->ch_sub;
+                unsigned m = tmask;
+                for (int e0 = 0; e0 < Emax; e0 += 6) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        const f4 g = *(const f4*)(gpc + (e0 + u) * 4);
+                        const int t = __builtin_ctz(m | 0x80000000u); // joint id of this rank (31 when exhausted)
+                        m &= m - 1u;
+                        const float b = (float)((sub >> t) & 1u);
+                        S.x += b * g.x; S.y += b * g.y; S.z += b * g.z;
+                    }
+                }
+            }
+            Q4 gq;
+            float lsum_p = 0.f, lsum_r = 0.f;
+            if (is_root) { // d/d(q_0) through qw = cur (x) q_0 only
+                Q4 gqw = {0.f, 0.f, 0.f, 0.f};
+                for (int e0 = 0; e0 < E; ++e0) {
+                    const f4 c = *(const f4*)(cqb + e0 * 4);
+                    gqw.w += c.x; gqw.x += c.y; gqw.y += c.z; gqw.z += c.w;
+                    if (last) { const f2 l = *(const f2*)(lpb + e0 * 2); lsum_p += l.x; lsum_r += l.y; }
+                }
+                gq = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, gqw);
+            } else { // dL/dM_j = own rotation term + S o_child^T
+                const float ox = icp->ch_off[0], oy = icp->ch_off[1], oz = icp->ch_off[2];
+                M3 X = gM;
+                X.m00 += S.x * ox; X.m01 += S.x * oy; X.m02 += S.x * oz;
+                X.m10 += S.y * ox; X.m11 += S.y * oy; X.m12 += S.y * oz;
+                X.m20 += S.z * ox; X.m21 += S.z * oy; X.m22 += S.z * oz;
+                gq = quat_mat_grad(q, X);
+            }
+            const float dot = q.w * gq.w + q.x * gq.x + q.y * gq.y + q.z * gq.z;
+            f4 gyv = {sd.x * (gq.w - q.w * dot) * inv, sd.y * (gq.x - q.x * dot) * inv,
+                      sd.z * (gq.y - q.y * dot) * inv, sd.w * (gq.z - q.z * dot) * inv};
+            if (is_disp) gyv = f4{sd.x * S.x, sd.y * S.y, sd.z * S.z, 0.f}; // ch_sub = every joint
+            if (dq >= 0) {
+                *(f4*)(yp + pf * S_Y + 4 * dq) = gyv; // gy aliases plane 0 of y
+                if (a.dbg && iter == 0 && fvalid) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_GY + 4 * dq) = gyv;
+            }
+
+            // ---- outputs of the last forward pass
+            if (last && fvalid) {
+                if (is_joint) {
+                    if (a.pose) {
+                        float* o = a.pose + (size_t)gfp * 88 + 4 * it_id;
+                        o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y;
+                        o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+                    }
+                    if (a.pos) {
+                        const V3 pw = mat_vec(R0, pr);
+                        float* o = a.pos + ((size_t)gfp * NJ + it_id) * 3;
+                        o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+                    }
+                    if (a.rot) {
+                        const M3 G = mat_mat(R0, M);
+                        float* o = a.rot + ((size_t)gfp * NJ + it_id) * 9;
+                        o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
+                    }
+                }
+                if (is_root) {
+                    if (a.world_rot) { float* o = a.world_rot + (size_t)gfp * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
+                    if (a.loss) { a.loss[(size_t)gfp * 3 + 0] = lsum_p; a.loss[(size_t)gfp * 3 + 1] = lsum_r; }
+                }
+                if (is_disp) {
+                    if (a.disp) { float* o = a.disp + (size_t)gfp * 3; o[0] = r.w; o[1] = r.x; o[2] = r.y; }
+                    if (a.world_disp) {
+                        const V3 wd = mat_vec(R0, V3{r.w, r.x, r.y});
+                        float* o = a.world_disp + (size_t)gfp * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
+                    }
+                }
+            }
+        }
+        if (!optimise) break; // forward-only launch (uniform)
+        float WB2[14]; // bL2 weights: issued before the barrier, landed by the time it opens
+        {
+            const f4 w0 = *(const f4*)(wbl), w1 = *(const f4*)(wbl + 4), w2 = *(const f4*)(wbl + 8);
+            const f2 w3 = *(const f2*)(wbl + 12);
+            WB2[0] = w0.x; WB2[1] = w0.y; WB2[2] = w0.z; WB2[3] = w0.w; WB2[4] = w1.x; WB2[5] = w1.y; WB2[6] = w1.z; WB2[7] = w1.w;
+            WB2[8] = w2.x; WB2[9] = w2.y; WB2[10] = w2.z; WB2[11] = w2.w; WB2[12] = w3.x; WB2[13] = w3.y;
+        }
+        __syncthreads();
+
+        // ================= bL2: d1 = (A2^T gy) * lrelu'(a1)  (92(+virtual quads) -> 60), 4 tiles x 2 halves
+        {
+            const int t = wave & 3, hf = wave >> 2;
+            const float* p = yp + f16 * S_Y;
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (hf == 0) { // steps 0..11: columns 0..47
+                float b[12];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const f4 v = *(const f4*)(p + 16 * s + 4 * h);
+                    b[4 * s + 0] = v.x; b[4 * s + 1] = v.y; b[4 * s + 2] = v.z; b[4 * s + 3] = v.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc = mfma4(WB2[i], b[i], acc);
+            } else { // steps 12..25: columns 48..103
+                float b[14];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const f4 v = *(const f4*)(p + 48 + 16 * s + 4 * h);
+                    b[4 * s + 0] = v.x; b[4 * s + 1] = v.y; b[4 * s + 2] = v.z; b[4 * s + 3] = v.w;
+                }
+                const f2 v2 = *(const f2*)(p + 96 + 2 * h);
+                b[12] = v2.x; b[13] = v2.y;
+#pragma unroll
+                for (int i = 0; i < 14; ++i) acc = mfma4(WB2[i], b[i], acc);
+            }
+            *(f4*)(a1p + (hf * FPB + f16) * S_D1 + 16 * t + 4 * h) = acc; // d1p aliases a1p
+        }
+        float WB1[8];
+        {
+            const f2 w0 = *(const f2*)(wbl + 14);
+            const f4 w1 = *(const f4*)(wbl + 16);
+            const f2 w2 = *(const f2*)(wbl + 20);
+            WB1[0] = w0.x; WB1[1] = w0.y; WB1[2] = w1.x; WB1[3] = w1.y; WB1[4] = w1.z; WB1[5] = w1.w; WB1[6] = w2.x; WB1[7] = w2.y;
+        }
+        __syncthreads();
+
+        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)  (60 -> 40), 3 tiles x 2 halves on waves 0..5
+        if (wave < 6) {
+            const int t = wave % 3, hf = wave / 3;
+            float d1[16];
+            load_row_sum<64>(a1p + f16 * S_D1, a1p + (FPB + f16) * S_D1, h, d1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d1[i] = dlrelu(a1f[i], d1[i]);
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = mfma4(WB1[i], hf ? d1[8 + i] : d1[i], acc);
+            *(f4*)(a0p + (hf * FPB + f16) * S_D0 + 16 * t + 4 * h) = acc; // d0p aliases a0p
+        }
+        float WB0[5];
+        {
+            const f2 w0 = *(const f2*)(wbl + 22), w1 = *(const f2*)(wbl + 24);
+            WB0[0] = w0.x; WB0[1] = w0.y; WB0[2] = w1.x; WB0[3] = w1.y; WB0[4] = wbl[26];
+        }
+        __syncthreads();
+
+        // ================= bL0: gz = A0^T d0  (40 -> 24), 2 tiles x 2 halves on waves 0..3
+        if (wave < 4) {
+            const int t = wave & 1, hf = wave >> 1;
+            float d0[10];
+            load_row_sum<40>(a0p + f16 * S_D0, a0p + (FPB + f16) * S_D0, h, d0);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) d0[i] = dlrelu(a0f[i], d0[i]);
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc = mfma4(WB0[i], hf ? d0[5 + i] : d0[i], acc);
+            *(f4*)(gzp + (hf * FPB + f16) * S_GZ + 16 * t + 4 * h) = acc;
+        }
+        __syncthreads();
+
+        // ================= Adam on z   (torch.optim.Adam, single-tensor form)
+        // every wave updates its own register copy of z; m and v live in LDS, double-buffered:
+        // all waves read buffer iter&1, wave 0 alone writes buffer (iter+1)&1.
+        {
+            float gz[6], ztf[6], mf[6], vf[6];
+            const int rb = (iter & 1) * FPB * S_AD, wb = ((iter + 1) & 1) * FPB * S_AD;
+            load_row_sum<24>(gzp + f16 * S_GZ, gzp + (FPB + f16) * S_GZ, h, gz);
+            load_row<24>(lds + L_ZT + f16 * S_AD, h, ztf);
+            load_row<24>(lds + L_ADM + rb + f16 * S_AD, h, mf);
+            load_row<24>(lds + L_ADV + rb + f16 * S_AD, h, vf);
+            const float step = a.tab.step[iter], bc2s = a.tab.bc2s[iter];
+            const bool wr_out = (wave == 0) && (blk0 + f16 < nB);
+            if (last) { // uniform: outputs that live on the latent lanes
+                float lt = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float dz = zf[i] - ztf[i];
+                    lt += dz * dz;
+                }
+                lt += __shfl_xor(lt, 16);
+                lt += __shfl_xor(lt, 32);
+                if (wr_out) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        if (a.z_pre) a.z_pre[(size_t)(blk0 + f16) * LAT + kcol(24, i, h)] = zf[i];
+                    if (a.loss && h == 0) a.loss[(size_t)(blk0 + f16) * 3 + 2] = lt * a.lam_tmp * (1.f / 24.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float g = gz[i] + a.ctmp * (zf[i] - ztf[i]);
+                if (a.dbg && iter == 0 && wr_out) a.dbg[(size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + kcol(24, i, h)] = g;
+                mf[i] = mf[i] + a.one_m_b1 * (g - mf[i]);
+                vf[i] = vf[i] * a.beta2 + a.one_m_b2 * g * g;
+                const float den = sqrtf(vf[i]) / bc2s + a.eps;
+                zf[i] = zf[i] - step * (mf[i] / den);
+            }
+            if (wave == 0) {
+                float* mo = lds + L_ADM + wb + f16 * S_AD;
+                float* vo = lds + L_ADV + wb + f16 * S_AD;
+                *(f4*)(mo + 4 * h) = f4{mf[0], mf[1], mf[2], mf[3]};
+                *(f2*)(mo + 16 + 2 * h) = f2{mf[4], mf[5]};
+                *(f4*)(vo + 4 * h) = f4{vf[0], vf[1], vf[2], vf[3]};
+                *(f2*)(vo + 16 + 2 * h) = f2{vf[4], vf[5]};
+            }
+        }
+    }
+
+    if (optimise && wave == 0 && blk0 + f16 < nB) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (a.z) a.z[(size_t)(blk0 + f16) * LAT + kcol(24, i, h)] = zf[i];
+        }
+        if (a.iters && h == 0) a.iters[blk0 + f16] = a.n_iter;
+    }
+}
+
+extern "C" hipError_t dp_launch_optimize(const KArgs* args, hipStream_t stream)
+{
+    const int grid = (args->n_frames + FPB - 1) / FPB;
+    hipLaunchKernelGGL(dp_optimize_kernel, dim3(grid), dim3(NTHREADS), 0, stream, *args);
+    return hipGetLastError();
+}
+
+extern "C" int dp_kernel_lds_bytes(void) { return L_TOTAL * 4; }

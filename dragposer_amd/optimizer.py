@@ -1,0 +1,136 @@
+"""Batched latent optimiser: the host-side operator over the C ABI (include/dragposer.h).
+
+`LatentOptimizer.optimize` runs, for B independent frames at once, what the reference's
+``DragPose.run`` does per frame in its while loop (python/src/drag_pose.py:296-355): decode ->
+FK -> tracker loss -> backward -> Adam on z, `n_iter` times, entirely inside one HIP kernel
+launch.  PyTorch is used for device memory and streams only: tensors are handed to the library as
+raw device pointers on torch's current stream.  There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import DEFAULT_MODEL, NJ, HostModel
+
+LATENT = 24
+
+_OUT_SPECS = {  # name -> (trailing shape, dtype)
+    "z": ((LATENT,), torch.float32),
+    "z_pre": ((LATENT,), torch.float32),
+    "pose": ((88,), torch.float32),
+    "disp": ((3,), torch.float32),
+    "world_disp": ((3,), torch.float32),
+    "world_rot": ((4,), torch.float32),
+    "pos": ((NJ, 3), torch.float32),
+    "rot": ((NJ, 9), torch.float32),
+    "loss": ((3,), torch.float32),
+    "iters": ((), torch.int32),
+}
+
+
+def _check(t, name, shape, dtype, device):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor on {device}")
+    if t.device != device:
+        raise ValueError(f"{name}: tensor is on {t.device}, the optimiser is on {device}")
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous {dtype} of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+class LatentOptimizer:
+    """One context per device.  Not thread-safe (same contract as the C ABI)."""
+
+    def __init__(self, model_path=DEFAULT_MODEL, device="cuda:0", weight_dtype="fp32", arrays=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("LatentOptimizer needs a ROCm device (cuda:N); there is no CPU fallback")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible to PyTorch; dragposer_amd has no CPU fallback")
+        self.host_model = HostModel(model_path, weight_dtype, arrays=arrays)
+        self.ctx = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        rc = self.lib.dp_create(C.byref(self.ctx), C.byref(self.host_model.struct), idx)
+        if rc != _lib.DP_OK:
+            raise _lib.DragPoserError(rc, _lib.last_error())
+        fpb, tpb, lds = C.c_int(), C.c_int(), C.c_int()
+        self.lib.dp_kernel_geometry(self.ctx, C.byref(fpb), C.byref(tpb), C.byref(lds))
+        self.frames_per_block, self.threads_per_block, self.lds_bytes = fpb.value, tpb.value, lds.value
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.dp_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _fail(self, rc):
+        raise _lib.DragPoserError(rc, _lib.last_error(self.ctx))
+
+    def _outputs(self, B, names, out):
+        res = _lib.DpResult()
+        tensors = {}
+        for name in names:
+            shape, dtype = _OUT_SPECS[name]
+            t = out[name] if out is not None and name in out else torch.empty((B,) + shape, dtype=dtype, device=self.device)
+            setattr(res, name, _check(t, name, (B,) + shape, dtype, self.device))
+            tensors[name] = t
+        return res, tensors
+
+    def optimize(self, z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter=50, lr=1e-2, betas=(0.9, 0.999),
+                 eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, outputs=None, out=None, _debug=None):
+        """All inputs are device tensors: z0/z_tgt [B,24], cur_rot [B,4], tgt_pos [B,22,3],
+        tgt_rot [B,22,9], w [B,22,2] (fp32) and tracked [B,22] (uint8).  Returns a dict of device
+        tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream."""
+        B = int(z0.shape[0])
+        dev = self.device
+        batch = _lib.DpBatch()
+        batch.n_frames = B
+        batch.z0 = _check(z0, "z0", (B, LATENT), torch.float32, dev)
+        batch.z_tgt = _check(z_tgt, "z_tgt", (B, LATENT), torch.float32, dev)
+        batch.cur_rot = _check(cur_rot, "cur_rot", (B, 4), torch.float32, dev)
+        batch.tgt_pos = _check(tgt_pos, "tgt_pos", (B, NJ, 3), torch.float32, dev)
+        batch.tgt_rot = _check(tgt_rot, "tgt_rot", (B, NJ, 9), torch.float32, dev)
+        batch.w = _check(w, "w", (B, NJ, 2), torch.float32, dev)
+        batch.tracked = _check(tracked, "tracked", (B, NJ), torch.uint8, dev)
+        p = _lib.DpParams(n_iter=int(n_iter), lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, lambda_rot=lambda_rot,
+                          lambda_tmp=lambda_tmp, early_stop=0, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=0.0)
+        names = tuple(outputs) if outputs is not None else tuple(_OUT_SPECS)
+        res, tensors = self._outputs(B, names, out)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if _debug is not None:
+            rc = self.lib.dp_optimize_debug(self.ctx, C.byref(batch), C.byref(p), C.byref(res),
+                                            C.c_void_p(_debug.data_ptr()), stream)
+        else:
+            rc = self.lib.dp_optimize(self.ctx, C.byref(batch), C.byref(p), C.byref(res), stream)
+        if rc != _lib.DP_OK:
+            self._fail(rc)
+        return tensors
+
+    def forward(self, z, cur_rot, outputs=("pose", "disp", "world_disp", "world_rot", "pos", "rot"), out=None):
+        """decode + FK of z [B,24] under cur_rot [B,4] (no loss, no update)."""
+        B = int(z.shape[0])
+        zp = _check(z, "z", (B, LATENT), torch.float32, self.device)
+        cp = _check(cur_rot, "cur_rot", (B, 4), torch.float32, self.device)
+        res, tensors = self._outputs(B, tuple(outputs), out)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.lib.dp_forward(self.ctx, B, C.c_void_p(zp), C.c_void_p(cp), C.byref(res), stream)
+        if rc != _lib.DP_OK:
+            self._fail(rc)
+        return tensors
+
+
+def to_device_batch(np_batch, device):
+    """numpy dict (z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked) -> device tensors."""
+    out = {}
+    for k in ("z0", "z_tgt", "cur_rot", "tgt_pos", "tgt_rot", "w"):
+        out[k] = torch.from_numpy(np.ascontiguousarray(np_batch[k], dtype=np.float32)).to(device)
+    out["tracked"] = torch.from_numpy(np.ascontiguousarray(np_batch["tracked"], dtype=np.uint8)).to(device)
+    return out

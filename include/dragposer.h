@@ -1,0 +1,141 @@
+/* dragposer.h -- C ABI of libdragposer_hip.so: DragPoser's per-frame latent optimisation on
+ * MI355X (gfx950), batched over independent frames.
+ *
+ * What each entry point replaces in the reference (UPC-ViRVIG/DragPoser, python/src):
+ *   dp_create / dp_destroy   the model state DragPose.__init__ keeps (drag_pose.py:13-45): frozen
+ *                            Decoder tensors (autoencoder.py:146-222, skeleton.py:44-52,231-242),
+ *                            dataset mean/std (drag_pose.py:27-34), skeleton parents/offsets
+ *   dp_optimize              the optimise loop of DragPose.run (drag_pose.py:296-355): Decoder.forward
+ *                            (autoencoder.py:224-256), DragPose.loss (drag_pose.py:66-194) with
+ *                            from_root_quat_to_rotmat + fk_rotmat (utils.py:80-149), loss.backward()
+ *                            and optim.Adam.step() (drag_pose.py:218,342-344) -- for B frames at once
+ *   dp_forward               Decoder.forward + the FK part of DragPose.loss (drag_pose.py:84-113) with
+ *                            no loss/backward: pose, world root transform and joint positions of z
+ *   dp_fold_decoder          host-only helper: the algebra the reference re-does every call
+ *                            (W*mask, skeleton.py:120; unpool matmul, skeleton.py:245) done once
+ *
+ * Conventions (the reference's: SURVEY.md 8.2): quaternions are (w,x,y,z) Hamilton; all arrays are
+ * fp32, row-major, frame-major; joint count 22, latent 24, decoder widths 24->40->60->92.
+ * Every function returns DP_OK (0) or a negative dp_status and never throws; the message of the
+ * last failure on a context is dp_last_error(ctx) (dp_last_error(NULL): last failure of dp_create
+ * on this thread).  The caller owns every buffer; a context owns only its device copy of the
+ * model.  dp_optimize / dp_forward are asynchronous on the given HIP stream and perform no
+ * allocation, no host synchronisation and no host<->device copy of caller data (graph-capturable).
+ * One context per device; a context is not thread-safe; distinct contexts are independent.
+ * There is NO CPU fallback: without a usable gfx950 device dp_create fails with DP_ERR_DEVICE.
+ */
+#ifndef DRAGPOSER_H
+#define DRAGPOSER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DP_VERSION 100 /* 0.1.0 */
+
+#define DP_NUM_JOINTS 22
+#define DP_LATENT 24
+#define DP_POSE_CHANNELS 88 /* 22 joints x 4 quaternion channels */
+#define DP_MAX_ITERS 512
+
+typedef enum dp_status {
+    DP_OK = 0,
+    DP_ERR_INVALID = -1,     /* NULL pointer, bad size, unsupported topology */
+    DP_ERR_DEVICE = -2,      /* no gfx950 device / HIP runtime failure */
+    DP_ERR_UNSUPPORTED = -3, /* valid request this build does not implement */
+    DP_ERR_LAUNCH = -4       /* kernel launch failed */
+} dp_status;
+
+typedef enum dp_weight_dtype {
+    DP_WEIGHTS_FP32 = 0,
+    DP_WEIGHTS_BF16 = 1 /* every decoder `weight` tensor rounded to bf16 (nearest-even) before folding;
+                           activations and accumulation stay fp32 (BASELINE config 5) */
+} dp_weight_dtype;
+
+typedef struct dp_ctx dp_ctx;
+
+/* Host pointers to the reference checkpoint's decoder tensors, fp32 row-major [out][in]
+ * (state_dict keys under autoencoder.decoder.*), plus statistics and skeleton. */
+typedef struct dp_model {
+    const float* f_latent_w; /* [24][24]  f_latent.weight */
+    const float* f_latent_b; /* [24]      f_latent.bias */
+    const float* unpool_w[3]; /* layers.l.0.weight : [40][24], [60][40], [92][60] */
+    const float* conv_w[3];   /* layers.l.1.weight : [40][40], [60][60], [92][92] (kernel size 1) */
+    const float* conv_mask[3]; /* layers.l.1.mask  : same shapes */
+    const float* conv_b[3];   /* layers.l.1.bias   : [40], [60], [92] */
+    const float* mean_q; /* [88] first 4 of every 8 channels of means["dqs"] (drag_pose.py:27-29) */
+    const float* std_q;  /* [88] same of stds["dqs"] */
+    const float* mean_disp; /* [3] */
+    const float* std_disp;  /* [3] */
+    const int* parents;     /* [22], parents[0] = 0, parents[j] < j */
+    const float* offsets;   /* [22][3], row 0 ignored (root offset is zero, train.py:340) */
+    int weight_dtype;       /* dp_weight_dtype */
+} dp_model;
+
+/* Folded decoder (three dense layers, LeakyReLU(0.2) after the first two). */
+typedef struct dp_folded {
+    float A0[40 * 24], c0[40];
+    float A1[60 * 40], b1[60];
+    float A2[92 * 60], b2[92];
+} dp_folded;
+
+/* Per-frame inputs, DEVICE pointers.  Tracked joints are given densely per joint:
+ * w[b][j] = (w_pos, w_rot) and tracked[b][j] != 0 where joint j carries a tracker in frame b
+ * (the reference's mask_joints / weights_joints, drag_pose.py:116-124); targets of untracked
+ * joints are ignored.  E_b = number of tracked joints sets the mean denominators 3 E_b, 9 E_b. */
+typedef struct dp_batch {
+    int n_frames;
+    const float* z0;      /* [B][24] warm-start latent (self.latent) */
+    const float* z_tgt;   /* [B][24] temporal prediction (target_latent, drag_pose.py:294) */
+    const float* cur_rot; /* [B][4]  current_global_rot */
+    const float* tgt_pos; /* [B][22][3] target_ee_pos scattered to joint slots */
+    const float* tgt_rot; /* [B][22][9] target_ee_rot (row-major 3x3) scattered to joint slots */
+    const float* w;       /* [B][22][2] */
+    const unsigned char* tracked; /* [B][22] */
+} dp_batch;
+
+typedef struct dp_params {
+    int n_iter;        /* max_iter; exactly n_iter iterations when early_stop == 0 (<= DP_MAX_ITERS) */
+    float lr;          /* learning_rate */
+    float beta1, beta2, eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+    float lambda_rot, lambda_tmp;
+    int early_stop;    /* 1: per-frame while-condition of drag_pose.py:300-304 */
+    float stop_eps_pos, stop_eps_rot, min_loss_incr;
+} dp_params;
+
+/* Outputs, DEVICE pointers; any may be NULL.  All but z are those of the LAST forward pass
+ * (the latent before the final Adam step), as the reference returns them (drag_pose.py:309-312). */
+typedef struct dp_result {
+    float* z;          /* [B][24] latent after the last Adam step (next frame's warm start) */
+    float* z_pre;      /* [B][24] latent of the last forward pass (current_latent) */
+    float* pose;       /* [B][88] decoder output: normalised-space unit quaternions, root incremental */
+    float* disp;       /* [B][3]  root-space displacement, de-normalised (metres) */
+    float* world_disp; /* [B][3]  */
+    float* world_rot;  /* [B][4]  */
+    float* pos;        /* [B][22][3] joint positions w.r.t. the previous frame's root position */
+    float* rot;        /* [B][22][9] global joint rotation matrices */
+    float* loss;       /* [B][3]  loss_pos, lambda_rot*loss_rot, lambda_tmp*loss_tmp */
+    int* iters;        /* [B]     iterations executed */
+} dp_result;
+
+int dp_version(void);
+const char* dp_last_error(const dp_ctx* ctx);
+
+/* host-only: fold the raw decoder tensors (double accumulation, fp32 result). */
+int dp_fold_decoder(const dp_model* model, dp_folded* out);
+
+int dp_create(dp_ctx** out, const dp_model* model, int device);
+int dp_destroy(dp_ctx* ctx);
+
+int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* params, const dp_result* out, void* hip_stream);
+
+/* decode + FK only; `out` fields z, z_pre, loss, iters are ignored. */
+int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float* cur_rot, const dp_result* out, void* hip_stream);
+
+/* introspection for the benchmark: frames per workgroup and workgroup size of the optimise kernel */
+int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRAGPOSER_H */
