@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: frames/s of the per-frame latent optimisation (6 trackers, 50 Adam
+iterations per frame) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (one dp_optimize launch: all 50 iterations of all frames)
+over the rank's batch of synthetic frames (recipe S of SURVEY.md 8d; targets are produced on the
+device with dp_forward).  Inputs are resident in HBM before the timed region.  Frames shard
+across ranks with no data-path collective (weak scaling: --frames per GPU); RCCL is used only
+for the barriers and the final metric reduction.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME_ITER = 35520  # folded decoder 24->40->60->92, forward + backward-to-input
+PEAK_F32_MFMA = 157.3e12     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak per GPU
+TRACK6 = [0, 3, 7, 13, 17, 21]
+W6 = {0: (10.0, 10.0), 3: (5.0, 0.01), 7: (5.0, 0.01), 13: (5.0, 0.01), 17: (5.0, 0.01), 21: (5.0, 0.01)}
+
+
+def synth_on_device(opt, B, seed, device):
+    """Recipe S, targets = FK(decode(Zs), CR) computed by the product's own forward kernel."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Zs = torch.randn(B, 24, generator=g) * 0.3
+    Z0 = torch.randn(B, 24, generator=g) * 0.3
+    ZT = Z0 + 0.05 * torch.randn(B, 24, generator=g)
+    CR = torch.randn(B, 4, generator=g)
+    CR = CR / torch.linalg.norm(CR, dim=-1, keepdim=True)
+    w = torch.zeros(B, 22, 2)
+    tracked = torch.zeros(B, 22, dtype=torch.uint8)
+    for j, wj in W6.items():
+        w[:, j] = torch.tensor(wj)
+        tracked[:, j] = 1
+    Zs, Z0, ZT, CR, w, tracked = (t.to(device).contiguous() for t in (Zs, Z0, ZT, CR, w, tracked))
+    fk = opt.forward(Zs, CR, outputs=("pos", "rot"))
+    m = tracked.to(torch.float32).unsqueeze(-1)
+    return dict(z0=Z0, z_tgt=ZT, cur_rot=CR, tgt_pos=(fk["pos"] * m).contiguous(), tgt_rot=(fk["rot"] * m).contiguous(),
+                w=w, tracked=tracked)
+
+
+def cpu_baseline(batch_np, n_iter, budget_s=20.0):
+    """The oracle ("port") timed on this host: reference-shaped B=1 autograd + torch.optim.Adam
+    loop, 1 thread, on a bounded sample of the same workload."""
+    from oracle import ref_torch as R
+    from oracle.analytic import AnalyticOracle
+
+    model = R.OracleModel()
+    torch.set_num_threads(1)
+    args = [batch_np[k] for k in ("z0", "z_tgt", "cur_rot", "tgt_pos", "tgt_rot", "w", "tracked")]
+    R.optimize_reference_shaped(model, *[a[:1] for a in args], n_iter)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 64 and time.perf_counter() - t0 < budget_s:
+        R.optimize_reference_shaped(model, *[a[n:n + 1] for a in args], n_iter)
+        n += 1
+    dt = time.perf_counter() - t0
+    out = dict(value=n / dt, unit="frames/s", cores=1, kind="port",
+               sample=f"{n} frames x {n_iter} iters, batch-1 PyTorch autograd + torch.optim.Adam loop (as the reference runs), 1 thread")
+    # extra context: the scalar C restatement of the same math (analytic backward), one core
+    A = AnalyticOracle(precision="f32")
+    nb = min(512, len(args[0]))
+    t0 = time.perf_counter()
+    A.optimize(*[a[:nb] for a in args], n_iter)
+    out["c_port_1core_frames_per_s"] = nb / (time.perf_counter() - t0)
+    out["host_cpus"] = os.cpu_count()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    opt = LatentOptimizer(device=device)
+    B, N = args.frames, args.iters
+    batch = synth_on_device(opt, B, 1234 + rank, device)
+    names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
+    out = opt.optimize(**batch, n_iter=N, outputs=names)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream the kernel is launched on
+    for _ in range(args.steps):
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+
+    # ---- parity on a sample (rank-local), reduced with the timing
+    err_mm = float("nan")
+    if not args.no_parity:
+        from oracle.analytic import AnalyticOracle
+
+        nb = min(256, B)
+        cpu = {k: v[:nb].cpu().numpy() for k, v in batch.items()}
+        ref = AnalyticOracle(precision="f32").optimize(cpu["z0"], cpu["z_tgt"], cpu["cur_rot"], cpu["tgt_pos"],
+                                                       cpu["tgt_rot"], cpu["w"], cpu["tracked"], N)
+        e = np.linalg.norm(out["pos"][:nb].cpu().numpy() - ref["pos"], axis=-1) * 1000.0
+        err_mm = float(np.percentile(e, 99))
+
+    stats = torch.tensor([dt, kern_ms, err_mm if err_mm == err_mm else -1.0], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)  # the only data collective: 3 doubles over RCCL
+    dt, kern_ms, err_mm = (float(x) for x in stats.cpu())
+
+    if rank == 0:
+        total_frames = B * world * args.steps
+        value = total_frames / dt
+        achieved = B * N * FLOP_PER_FRAME_ITER / (kern_ms * 1e-3)
+        res = {
+            "metric": "frames/sec (6 trackers, 50 iters/frame)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"S1: {B} synthetic frames per GPU, 6 trackers [0,3,7,13,17,21], {N} Adam iters/frame, fp32 "
+                                   f"(BASELINE north_star: 4096-frame batch)",
+                       "frames_per_gpu": B, "iters": N, "parallelism": f"frames sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+                         "kernel": "dp_optimize_kernel", "kernel_ms": kern_ms,
+                         "flop_per_launch": B * N * FLOP_PER_FRAME_ITER,
+                         "hbm_algorithmic_GBps": B * 1264 / (kern_ms * 1e-3) / 1e9},
+            "parity_p99_mm_vs_oracle": err_mm,  # 256 frames x 22 joints vs the C oracle (fp32)
+        }
+        if not args.no_cpu_baseline:
+            cpu = {k: v[:64].cpu().numpy() for k, v in batch.items()}
+            res["cpu_baseline"] = cpu_baseline(cpu, N)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dragposer.h declares, and its
+host-only logic (decoder folding, skeleton tables, argument validation) is right.  No compute
+call is made here: without a GPU dp_create must fail loudly with DP_ERR_DEVICE."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from dragposer_amd import _lib
+from dragposer_amd.model import HostModel
+from oracle.analytic import AnalyticOracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dragposer.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(dp_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.PUBLIC_SYMBOLS), declared ^ set(_lib.PUBLIC_SYMBOLS)
+    lib = _lib.load()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.dp_version() == 100
+
+
+def test_struct_layouts_match_header_sizes():
+    ptr = C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.DpModel) == 20 * ptr + 8  # 20 pointers + int (+pad)
+    assert C.sizeof(_lib.DpBatch) == 8 + 7 * ptr
+    assert C.sizeof(_lib.DpParams) == 11 * 4
+    assert C.sizeof(_lib.DpResult) == 10 * ptr
+    assert C.sizeof(_lib.DpFolded) == 4 * (40 * 24 + 40 + 60 * 40 + 60 + 92 * 60 + 92)
+
+
+@pytest.mark.parametrize("wd", ["fp32", "bf16"])
+def test_fold_decoder_matches_oracle_fold(wd):
+    f, _ = HostModel(weight_dtype=wd).fold()
+    fo = AnalyticOracle(weight_rounding="bf16" if wd == "bf16" else "none").folded()
+    for k in f:
+        np.testing.assert_array_equal(f[k], fo[k])
+    assert np.count_nonzero(f["A2"]) < f["A2"].size  # joint-block structure survives folding
+
+
+def test_fold_rejects_null_pointers():
+    lib = _lib.load()
+    m = _lib.DpModel()
+    out = _lib.DpFolded()
+    assert lib.dp_fold_decoder(C.byref(m), C.byref(out)) == _lib.DP_ERR_INVALID
+    assert "NULL" in _lib.last_error()
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_create_fails_loudly_without_gpu():
+    lib = _lib.load()
+    hm = HostModel()
+    ctx = C.c_void_p()
+    rc = lib.dp_create(C.byref(ctx), C.byref(hm.struct), 0)
+    assert rc == _lib.DP_ERR_DEVICE and not ctx.value
+    assert "no CPU fallback" in _lib.last_error()
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_python_operator_has_no_cpu_fallback():
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    with pytest.raises((RuntimeError, ValueError)):
+        LatentOptimizer(device="cuda:0")
+    with pytest.raises(ValueError):
+        LatentOptimizer(device="cpu")
+
+
+def test_item_table_and_skeleton_validation():
+    import kernel_emu as KE
+
+    hm = HostModel()
+    _, _, items = KE.host_tables(hm)
+    kinds = list(items["kind"])
+    assert kinds[0] == 1 and kinds[1:22] == [0] * 21 and kinds[22] == 2
+    assert kinds[23:25] == [3, 3] and list(items["src_quad"][23:25]) == [11, 11]  # joint 11's extra children
+    assert sorted([int(items["ch_id"][11]), int(items["ch_id"][23]), int(items["ch_id"][24])]) == [12, 14, 18]
+    # path of joint 17 (left wrist): 9,10,11,14,15,16,17
+    p = [(int(items["path_lo"][17]) >> (5 * i)) & 31 for i in range(6)] + [int(items["path_hi"][17]) & 31]
+    assert sorted(p) == [9, 10, 11, 14, 15, 16, 17]
+    assert int(items["ch_sub"][22]) == (1 << 22) - 1
+    # a non-topological parents array is rejected
+    lib = _lib.load()
+    bad = HostModel()
+    bad.parents[5] = 7
+    buf = np.zeros(32 * 32, np.float32)
+    assert lib.dp_debug_items(C.byref(bad.struct), buf.ctypes.data_as(C.c_void_p)) == _lib.DP_ERR_INVALID

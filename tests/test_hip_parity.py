@@ -1,0 +1,197 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Tolerances (FK joint positions, all 22 joints, millimetres, evaluated at the latent of the last
+forward pass, like the reference's returned pose) are SURVEY.md 8(d)'s:
+  S1 / S4 (6 trackers, 50 iters): max <= 0.05 mm        (observed fp32 re-association noise ~0.001 mm)
+  S3 (3 trackers, 100 iters):     mean <= 0.05 mm, p99 <= 1 mm (chaotic under Adam's sign sensitivity:
+                                  two CPU runs of the same torch ops already differ by up to 6 mm)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from oracle.analytic import AnalyticOracle
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("z0", "z_tgt", "cur_rot", "tgt_pos", "tgt_rot", "w", "tracked")
+
+
+def _mm(a, b):
+    return np.linalg.norm(a - b, axis=-1) * 1000.0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def opt(dev):
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    return LatentOptimizer(device=dev)
+
+
+@pytest.fixture(scope="module")
+def opt_bf16(dev):
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    return LatentOptimizer(device=dev, weight_dtype="bf16")
+
+
+def _run(o, g, n_iter, lam, **kw):
+    from dragposer_amd.optimizer import to_device_batch
+
+    out = o.optimize(**to_device_batch(g, o.device), n_iter=n_iter, lambda_tmp=lam, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_native_library_is_what_runs(opt):
+    from dragposer_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libdragposer_hip.so" in maps
+    assert opt.frames_per_block == 16 and opt.threads_per_block == 512
+
+
+def test_forward_matches_oracle(opt, dev):
+    m = R.OracleModel()
+    b = R.synth_inputs(m, 100)  # ragged: 100 = 6 blocks + 4 frames
+    o = opt.forward(torch.from_numpy(b["z_src"]).to(dev), torch.from_numpy(b["cur_rot"]).to(dev))
+    torch.cuda.synchronize()
+    f = AnalyticOracle(precision="f64").forward(b["z_src"], b["cur_rot"])
+    assert _mm(o["pos"].cpu().numpy(), f["pos"]).max() < 0.005
+    np.testing.assert_allclose(o["rot"].cpu().numpy(), f["rot"], atol=1e-5)
+    np.testing.assert_allclose(o["world_rot"].cpu().numpy(), f["world_rot"], atol=2e-6)
+    np.testing.assert_allclose(o["world_disp"].cpu().numpy(), f["world_disp"], atol=2e-7)
+    np.testing.assert_allclose(o["pose"].cpu().numpy(), f["pose"], atol=1e-3)  # normalised space (/sigma ~ 1700x)
+    # the targets of recipe S are exactly this forward pass
+    trk = b["tracked"].astype(bool)
+    assert _mm(o["pos"].cpu().numpy()[trk], b["tgt_pos"][trk]).max() < 0.005
+
+
+@pytest.mark.parametrize("name", ["s1", "s3", "s4"])
+def test_first_iteration_gradient_and_losses(opt, opt_bf16, dev, golden_dir, name):
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, f"{name}.npz"))
+    mt = g["meta"]
+    o = opt_bf16 if mt["weight_rounding"] == "bf16" else opt
+    dbg = torch.zeros(len(g["z0"]), 240, device=dev)
+    out = o.optimize(**to_device_batch(g, dev), n_iter=1, lambda_tmp=mt["lambda_tmp"], _debug=dbg)
+    torch.cuda.synchronize()
+    A = AnalyticOracle(precision="f64", weight_rounding=mt["weight_rounding"])
+    lo, gr = A.grad(*[g[k] for k in KEYS], 1.0, mt["lambda_tmp"])
+    np.testing.assert_allclose(dbg.cpu().numpy()[:, 208:232], gr, atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), g["loss_hist"][:, 0], rtol=1e-5, atol=1e-9)  # reference's own losses
+    # Adam step 1 moves every component by exactly lr
+    dz = out["z"].cpu().numpy() - g["z0"]
+    big = np.abs(gr) > 1e-3  # where eps=1e-8 is negligible against |g|
+    np.testing.assert_allclose(dz[big], -0.01 * np.sign(gr[big]), atol=2e-7)
+    ref1 = A.optimize(*[g[k] for k in KEYS], 1, lam_tmp=mt["lambda_tmp"])["z_final"]
+    np.testing.assert_allclose(out["z"].cpu().numpy(), ref1, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["s1", "s4"])
+def test_golden_parity_6_trackers(opt, opt_bf16, golden_dir, name):
+    g = R.load_golden(os.path.join(golden_dir, f"{name}.npz"))
+    mt = g["meta"]
+    o = _run(opt_bf16 if mt["weight_rounding"] == "bf16" else opt, g, mt["n_iter"], mt["lambda_tmp"])
+    err = _mm(o["pos"], g["pos"])
+    assert err.max() <= 0.05, err.max()
+    np.testing.assert_allclose(o["z"], g["z_final"], atol=5e-5)
+    np.testing.assert_allclose(o["z_pre"], g["z_pre"], atol=5e-5)
+    np.testing.assert_allclose(o["world_rot"], g["world_rot"], atol=5e-6)
+    np.testing.assert_allclose(o["world_disp"], g["world_disp"], atol=5e-7)
+    np.testing.assert_allclose(o["rot"], g["rot"], atol=2e-5)
+    np.testing.assert_allclose(o["pose"], g["pose"], atol=2e-3)
+    np.testing.assert_allclose(o["loss"], g["loss_hist"][:, -1], rtol=2e-3, atol=1e-8)
+    assert np.all(o["iters"] == mt["n_iter"])
+
+
+def test_golden_parity_3_trackers_100_iters(opt, golden_dir):
+    g = R.load_golden(os.path.join(golden_dir, "s3.npz"))
+    mt = g["meta"]
+    o = _run(opt, g, mt["n_iter"], mt["lambda_tmp"])
+    err = _mm(o["pos"], g["pos"])
+    assert err.mean() <= 0.05 and np.percentile(err, 99) <= 1.0, (err.mean(), np.percentile(err, 99), err.max())
+    tot_ref, tot = g["loss_hist"][:, -1].sum(1), o["loss"].sum(1)
+    np.testing.assert_allclose(tot, tot_ref, rtol=5e-2)  # same optimum quality even where the path diverged
+    # max is reported, not gated at SURVEY's 3 mm: the batch-1 reference and the batched torch restatement of
+    # the very same ops differ by 6.2 mm on one frame of this fixture (tests/test_oracle.py)
+    assert err.max() <= 10.0, err.max()
+
+
+@pytest.mark.parametrize("B", [1, 15, 17, 33])
+def test_ragged_batches_equal_full_batch_rows(opt, golden_dir, B):
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    full = _run(opt, g, 20, 0.02)
+    sub = _run(opt, {k: g[k][:B] for k in KEYS}, 20, 0.02)
+    for k in ("z", "pos", "pose", "loss"):
+        np.testing.assert_array_equal(sub[k], full[k][:B])  # a frame's result never depends on its batch
+
+
+def test_full_size_batch_properties(opt, dev):
+    """BASELINE config (4096 frames x 50 iters): determinism, batch-position invariance, parity
+    against the C oracle on every frame, and the optimiser actually optimises."""
+    from dragposer_amd.optimizer import to_device_batch
+
+    m = R.OracleModel()
+    b = R.synth_inputs(m, 4096)
+    d = to_device_batch(b, dev)
+    o1 = {k: v.cpu().numpy() for k, v in opt.optimize(**d, n_iter=50).items()}
+    o2 = {k: v.cpu().numpy() for k, v in opt.optimize(**d, n_iter=50).items()}
+    for k in o1:
+        np.testing.assert_array_equal(o1[k], o2[k])  # bitwise reproducible
+    perm = np.random.RandomState(0).permutation(4096)
+    dp = to_device_batch({k: b[k][perm] for k in KEYS}, dev)
+    o3 = opt.optimize(**dp, n_iter=50)
+    np.testing.assert_array_equal(o3["z"].cpu().numpy(), o1["z"][perm])
+    ref = AnalyticOracle(precision="f32").optimize(*[b[k] for k in KEYS], 50)
+    # At 4096 frames the 0.05 mm max of the 64-frame fixtures becomes a statistical bound: Adam's first
+    # steps move by +-lr whatever |g|, so a rounding-level sign flip of a near-zero gradient component sends
+    # a frame down another path.  Measured between CPU oracles on this very batch (C f32 / C f64 / torch
+    # f32): 1-2 frames of 4096 beyond 0.05 mm (up to 3.2 mm), p99.9 0.0012 mm, mean 0.0004 mm.
+    err = _mm(o1["pos"], ref["pos"])
+    outliers = int((err.max(axis=1) > 0.05).sum())
+    assert np.percentile(err, 99.9) <= 0.01 and err.mean() <= 0.002 and outliers <= 8 and err.max() <= 10.0, (
+        np.percentile(err, 99.9), err.mean(), outliers, err.max())
+    first = opt.optimize(**d, n_iter=1)["loss"].cpu().numpy().sum(1)
+    assert (o1["loss"].sum(1) < first).mean() > 0.99
+    assert np.isfinite(o1["z"]).all()
+
+
+def test_argument_validation(opt, dev, golden_dir):
+    from dragposer_amd import _lib
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    d = to_device_batch(g, dev)
+    with pytest.raises(_lib.DragPoserError) as e:
+        opt.optimize(**d, n_iter=257)
+    assert e.value.code == _lib.DP_ERR_INVALID
+    with pytest.raises(ValueError):
+        opt.optimize(**{**d, "w": d["w"].double()}, n_iter=5)
+    with pytest.raises(ValueError):
+        opt.optimize(**{**d, "z0": d["z0"].cpu()}, n_iter=5)
+
+
+def test_untracked_frame_only_feels_the_temporal_pull(opt, dev, golden_dir):
+    """Edge case: a frame with no tracker at all (E_b = 0) must not produce NaN; z moves towards z_tgt."""
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    b = {k: g[k][:16].copy() for k in KEYS}
+    b["tracked"][3] = 0
+    b["w"][3] = 0
+    o = {k: v.cpu().numpy() for k, v in opt.optimize(**to_device_batch(b, dev), n_iter=30, lambda_tmp=0.5).items()}
+    assert np.isfinite(o["z"]).all() and np.isfinite(o["pos"]).all()
+    assert np.abs(o["z"][3] - b["z_tgt"][3]).max() < np.abs(b["z0"][3] - b["z_tgt"][3]).max()
+    assert o["loss"][3, 0] == 0 and o["loss"][3, 1] == 0
