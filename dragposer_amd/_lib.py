@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdragposer_hip.so")
+LIB_PATH = os.environ.get("DRAGPOSER_LIB", os.path.join(HERE, "lib", "libdragposer_hip.so"))  # override: diagnostic builds
 
 DP_OK = 0
 DP_ERR_INVALID = -1

@@ -381,7 +381,7 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         b1t *= (double)p->beta1;
         b2t *= (double)p->beta2;
         k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
-        k.tab.bc2s[t] = (float)std::sqrt(1.0 - b2t);
+        k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
     }
     return launch(ctx, k, stream);
 }

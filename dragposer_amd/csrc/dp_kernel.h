@@ -5,7 +5,7 @@
 
 struct AdamTab { // per-iteration scalars torch's single-tensor Adam computes in Python doubles
     float step[dpl::MAX_ITERS]; // lr / (1 - beta1^t)
-    float bc2s[dpl::MAX_ITERS]; // sqrt(1 - beta2^t)
+    float bc2s[dpl::MAX_ITERS]; // 1 / sqrt(1 - beta2^t)
 };
 
 // debug dump (iteration 0 only), floats per frame

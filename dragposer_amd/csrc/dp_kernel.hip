@@ -24,6 +24,23 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define DEV __device__ __forceinline__
 
+// Diagnostic build (-DDP_PROFILE): wave 0 of every workgroup accumulates s_memtime deltas per phase
+// and stores 20 x u64 per workgroup into the debug buffer.  Never part of the shipped library.
+#ifdef DP_PROFILE
+#define STAMP(i)                                                     \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+        prof[i] += t_ - tprev;                                       \
+        tprev = t_;                                                  \
+        __builtin_amdgcn_sched_barrier(0);                           \
+    } while (0)
+#define DBG_DUMP 0
+#else
+#define STAMP(i)
+#define DBG_DUMP 1
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // LDS map (floats)
 constexpr int L_A0 = 0;                            // a0p[2][16][S_A0]   (aliased by d0p)
@@ -204,7 +221,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         }
     }
 
-    // ---- P3 per-lane identity and per-frame tracker inputs
+    // ---- P3 per-lane identity (a few integers stay in registers, the float constants are re-read from
+    //      LDS every iteration to keep the register budget for the kinematics temporaries)
+    const int sq = icp->src_quad, dq = icp->dst_quad;
+    const int ch_id = icp->ch_id;
+    const unsigned ch_sub = icp->ch_sub, plo = icp->path_lo, phi = icp->path_hi;
     const int kind = icp->kind;
     const bool is_joint = kind == KIND_JOINT || kind == KIND_ROOT; // owns a tracker slot / outputs
     const bool has_quat = kind != KIND_DISP && kind != KIND_IDLE;
@@ -241,6 +262,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
     float a0f[10], a1f[16];
     __syncthreads();
+#ifdef DP_PROFILE
+    unsigned long long prof[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
@@ -254,7 +279,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             for (int i = 0; i < 3; ++i) acc = mfma4(W[W_OFF_L0 + i], hf ? zf[3 + i] : zf[i], acc);
             *(f4*)(a0p + (hf * FPB + f16) * S_A0 + 16 * t + 4 * h) = acc;
         }
+        STAMP(0);
         __syncthreads();
+        STAMP(1);
 
         // ================= L1: a1 = A1 lrelu(a0) + b1 (40 -> 60), 4 tiles x 2 halves
         load_row_sum<40>(a0p + f16 * S_A0, a0p + (FPB + f16) * S_A0, h, a0f);
@@ -268,7 +295,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             for (int i = 0; i < 5; ++i) acc = mfma4(W[W_OFF_L1 + i], hf ? a0f[5 + i] : a0f[i], acc);
             *(f4*)(a1p + (hf * FPB + f16) * S_A1 + 16 * t + 4 * h) = acc;
         }
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
 
         // ================= L2: y = A2 lrelu(a1) + b2 (60 -> 92), 6 tiles x 2 halves = 12 chunks
         load_row_sum<64>(a1p + f16 * S_A1, a1p + (FPB + f16) * S_A1, h, a1f);
@@ -291,17 +320,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             }
             *(f4*)(yp + (hf * FPB + f16) * S_Y + 16 * t + 4 * h) = acc0;
         }
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
 
         // ================= P3: normalise, FK, loss, backward to gy   (wave-private rows)
         {
-            const int sq = icp->src_quad, dq = icp->dst_quad;
             const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
-            if (a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
+            if (DBG_DUMP && a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
             const f4 sd = *(const f4*)icp->sd, mu = *(const f4*)icp->mu;
+            const f4 cho = *(const f4*)icp->ch_off; // child offset (x,y,z) | ch_id
+            f4 t0, t1, t2, t3;                      // tracker inputs of my joint (tracked lanes only)
+            if (trk) {
+                t0 = *(const f4*)(tin->tp);     // tp, cgp
+                t1 = *(const f4*)(tin->tR);     // tR[0..3]
+                t2 = *(const f4*)(tin->tR + 4); // tR[4..7]
+                t3 = *(const f4*)(tin->tR + 8); // tR[8], cgr, clp, clr
+            }
             const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
             const float nn = r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z;
-            const float inv = has_quat ? 1.0f / sqrtf(nn) : 0.f;
+            const float inv = has_quat ? __builtin_amdgcn_rsqf(nn) : 0.f;
             const Q4 q = {r.w * inv, r.x * inv, r.y * inv, r.z * inv};
             M3 M = quat_to_mat(q);
             if (is_root) {
@@ -311,10 +349,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             }
             if (is_disp) *(f4*)(qdb + 4) = f4{r.w, r.x, r.y, 0.f};
             {
-                const V3 u = mat_vec(M, V3{icp->ch_off[0], icp->ch_off[1], icp->ch_off[2]});
-                *(f4*)(bone + icp->ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
+                const V3 u = mat_vec(M, V3{cho.x, cho.y, cho.z});
+                *(f4*)(bone + ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
             }
             wave_sync();
+            STAMP(6);
 
             const f4 qwv = *(const f4*)(qdb);
             const f4 dv = *(const f4*)(qdb + 4);
@@ -322,20 +361,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             const M3 R0 = quat_to_mat(qw);
             V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
             {
-                const unsigned plo = icp->path_lo, phi = icp->path_hi;
+                f4 b[MAX_PATH];
 #pragma unroll
                 for (int i = 0; i < MAX_PATH; ++i) {
                     const unsigned k = (i < 6) ? ((plo >> (5 * i)) & 31u) : (phi & 31u);
-                    const f4 b = *(const f4*)(bone + k * 4);
-                    pr.x += b.x; pr.y += b.y; pr.z += b.z;
+                    b[i] = *(const f4*)(bone + k * 4);
                 }
+#pragma unroll
+                for (int i = 0; i < MAX_PATH; ++i) { pr.x += b[i].x; pr.y += b[i].y; pr.z += b[i].z; }
             }
             M3 gM = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (trk) { // tracker terms in the root frame
-                const f4 t0 = *(const f4*)(tin->tp);     // tp, cgp
-                const f4 t1 = *(const f4*)(tin->tR);     // tR[0..3]
-                const f4 t2 = *(const f4*)(tin->tR + 4); // tR[4..7]
-                const f4 t3 = *(const f4*)(tin->tR + 8); // tR[8], cgr, clp, clr
                 const V3 tp = {t0.x, t0.y, t0.z};
                 const M3 tR = {t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x};
                 const float cgp = t0.w, cgr = t3.y;
@@ -363,39 +399,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                 }
             }
             wave_sync();
+            STAMP(7);
 
-            // subtree sum of the tracker gradients below my child bone
+            // subtree sum of the tracker gradients below my child bone; on the root lane also the sum of the
+            // trackers' contributions to dL/d(qw) and (last iteration) of their loss terms
             V3 S = {0.f, 0.f, 0.f};
+            Q4 gqw = {0.f, 0.f, 0.f, 0.f};
+            float lsum_p = 0.f, lsum_r = 0.f;
             {
-                const unsigned sub = icp->ch_sub;
                 unsigned m = tmask;
                 for (int e0 = 0; e0 < Emax; e0 += 6) {
+                    f4 g[6], c[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(gpc + (e0 + u) * 4);
+                    if (is_root) {
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(cqb + (e0 + u) * 4);
+                        if (last) {
+#pragma unroll
+                            for (int u = 0; u < 6; ++u) { const f2 l = *(const f2*)(lpb + (e0 + u) * 2); lsum_p += l.x; lsum_r += l.y; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
+                    }
 #pragma unroll
                     for (int u = 0; u < 6; ++u) {
-                        const f4 g = *(const f4*)(gpc + (e0 + u) * 4);
                         const int t = __builtin_ctz(m | 0x80000000u); // joint id of this rank (31 when exhausted)
                         m &= m - 1u;
-                        const float b = (float)((sub >> t) & 1u);
-                        S.x += b * g.x; S.y += b * g.y; S.z += b * g.z;
+                        const float b = (float)((ch_sub >> t) & 1u);
+                        S.x += b * g[u].x; S.y += b * g[u].y; S.z += b * g[u].z;
                     }
                 }
             }
             Q4 gq;
-            float lsum_p = 0.f, lsum_r = 0.f;
             if (is_root) { // d/d(q_0) through qw = cur (x) q_0 only
-                Q4 gqw = {0.f, 0.f, 0.f, 0.f};
-                for (int e0 = 0; e0 < E; ++e0) {
-                    const f4 c = *(const f4*)(cqb + e0 * 4);
-                    gqw.w += c.x; gqw.x += c.y; gqw.y += c.z; gqw.z += c.w;
-                    if (last) { const f2 l = *(const f2*)(lpb + e0 * 2); lsum_p += l.x; lsum_r += l.y; }
-                }
                 gq = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, gqw);
             } else { // dL/dM_j = own rotation term + S o_child^T
-                const float ox = icp->ch_off[0], oy = icp->ch_off[1], oz = icp->ch_off[2];
                 M3 X = gM;
-                X.m00 += S.x * ox; X.m01 += S.x * oy; X.m02 += S.x * oz;
-                X.m10 += S.y * ox; X.m11 += S.y * oy; X.m12 += S.y * oz;
-                X.m20 += S.z * ox; X.m21 += S.z * oy; X.m22 += S.z * oz;
+                X.m00 += S.x * cho.x; X.m01 += S.x * cho.y; X.m02 += S.x * cho.z;
+                X.m10 += S.y * cho.x; X.m11 += S.y * cho.y; X.m12 += S.y * cho.z;
+                X.m20 += S.z * cho.x; X.m21 += S.z * cho.y; X.m22 += S.z * cho.z;
                 gq = quat_mat_grad(q, X);
             }
             const float dot = q.w * gq.w + q.x * gq.x + q.y * gq.y + q.z * gq.z;
@@ -404,7 +447,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             if (is_disp) gyv = f4{sd.x * S.x, sd.y * S.y, sd.z * S.z, 0.f}; // ch_sub = every joint
             if (dq >= 0) {
                 *(f4*)(yp + pf * S_Y + 4 * dq) = gyv; // gy aliases plane 0 of y
-                if (a.dbg && iter == 0 && fvalid) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_GY + 4 * dq) = gyv;
+                if (DBG_DUMP && a.dbg && iter == 0 && fvalid) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_GY + 4 * dq) = gyv;
             }
 
             // ---- outputs of the last forward pass
@@ -447,7 +490,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             WB2[0] = w0.x; WB2[1] = w0.y; WB2[2] = w0.z; WB2[3] = w0.w; WB2[4] = w1.x; WB2[5] = w1.y; WB2[6] = w1.z; WB2[7] = w1.w;
             WB2[8] = w2.x; WB2[9] = w2.y; WB2[10] = w2.z; WB2[11] = w2.w; WB2[12] = w3.x; WB2[13] = w3.y;
         }
+        STAMP(8);
         __syncthreads();
+        STAMP(9);
 
         // ================= bL2: d1 = (A2^T gy) * lrelu'(a1)  (92(+virtual quads) -> 60), 4 tiles x 2 halves
         {
@@ -484,7 +529,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             const f2 w2 = *(const f2*)(wbl + 20);
             WB1[0] = w0.x; WB1[1] = w0.y; WB1[2] = w1.x; WB1[3] = w1.y; WB1[4] = w1.z; WB1[5] = w1.w; WB1[6] = w2.x; WB1[7] = w2.y;
         }
+        STAMP(10);
         __syncthreads();
+        STAMP(11);
 
         // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)  (60 -> 40), 3 tiles x 2 halves on waves 0..5
         if (wave < 6) {
@@ -503,7 +550,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             const f2 w0 = *(const f2*)(wbl + 22), w1 = *(const f2*)(wbl + 24);
             WB0[0] = w0.x; WB0[1] = w0.y; WB0[2] = w1.x; WB0[3] = w1.y; WB0[4] = wbl[26];
         }
+        STAMP(12);
         __syncthreads();
+        STAMP(13);
 
         // ================= bL0: gz = A0^T d0  (40 -> 24), 2 tiles x 2 halves on waves 0..3
         if (wave < 4) {
@@ -517,7 +566,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             for (int i = 0; i < 5; ++i) acc = mfma4(WB0[i], hf ? d0[5 + i] : d0[i], acc);
             *(f4*)(gzp + (hf * FPB + f16) * S_GZ + 16 * t + 4 * h) = acc;
         }
+        STAMP(14);
         __syncthreads();
+        STAMP(15);
 
         // ================= Adam on z   (torch.optim.Adam, single-tensor form)
         // every wave updates its own register copy of z; m and v live in LDS, double-buffered:
@@ -529,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             load_row<24>(lds + L_ZT + f16 * S_AD, h, ztf);
             load_row<24>(lds + L_ADM + rb + f16 * S_AD, h, mf);
             load_row<24>(lds + L_ADV + rb + f16 * S_AD, h, vf);
-            const float step = a.tab.step[iter], bc2s = a.tab.bc2s[iter];
+            const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
             const bool wr_out = (wave == 0) && (blk0 + f16 < nB);
             if (last) { // uniform: outputs that live on the latent lanes
                 float lt = 0.f;
@@ -550,11 +601,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const float g = gz[i] + a.ctmp * (zf[i] - ztf[i]);
-                if (a.dbg && iter == 0 && wr_out) a.dbg[(size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + kcol(24, i, h)] = g;
+                if (DBG_DUMP && a.dbg && iter == 0 && wr_out) a.dbg[(size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + kcol(24, i, h)] = g;
                 mf[i] = mf[i] + a.one_m_b1 * (g - mf[i]);
                 vf[i] = vf[i] * a.beta2 + a.one_m_b2 * g * g;
-                const float den = sqrtf(vf[i]) / bc2s + a.eps;
-                zf[i] = zf[i] - step * (mf[i] / den);
+                const float den = __builtin_amdgcn_sqrtf(vf[i]) * rbc2s + a.eps;
+                zf[i] = zf[i] - step * (mf[i] * __builtin_amdgcn_rcpf(den));
             }
             if (wave == 0) {
                 float* mo = lds + L_ADM + wb + f16 * S_AD;
@@ -565,7 +616,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                 *(f2*)(vo + 16 + 2 * h) = f2{vf[4], vf[5]};
             }
         }
+        STAMP(16);
     }
+#ifdef DP_PROFILE
+    if (a.dbg && tid == 0) {
+        unsigned long long* o = (unsigned long long*)a.dbg + (size_t)blockIdx.x * 20;
+        for (int i = 0; i < 20; ++i) o[i] = prof[i];
+    }
+#endif
 
     if (optimise && wave == 0 && blk0 + f16 < nB) {
 #pragma unroll

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of dp_optimize_kernel from the -DDP_PROFILE build
+(in-kernel s_memtime stamps taken by wave 0 of every workgroup).  Shares only -- the stamped
+build's run time is never quoted.  Run on the GPU box:
+    hipcc ... -DDP_PROFILE -o gpurun_out/libdp_prof.so ...; DRAGPOSER_LIB=gpurun_out/libdp_prof.so python tools/profile_phases.py
+"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_torch as R
+from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
+
+NAMES = ["L0 mfma", "bar1", "L1 load+mfma", "bar2", "L2 load+mfma", "bar3", "P3a normalise/bones", "P3b tracker terms",
+         "P3c gather/backward/out", "bar4", "bL2", "bar5", "bL1", "bar6", "bL0", "bar7", "Adam"]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = 50
+dev = torch.device("cuda:0")
+opt = LatentOptimizer(device=dev)
+b = R.synth_inputs(R.OracleModel(), B)
+d = to_device_batch(b, dev)
+grid = (B + 15) // 16
+dbg = torch.zeros(grid * 40 + 64, device=dev)
+for _ in range(3):
+    opt.optimize(**d, n_iter=N, _debug=dbg)
+torch.cuda.synchronize()
+p = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20)[:, :17].astype(np.float64) / N
+tot = p.sum(1)
+print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
+for i, n in enumerate(NAMES):
+    print(f"  {n:26s} {p[:, i].mean():8.0f}  {100 * p[:, i].mean() / tot.mean():5.1f}%")
