@@ -96,7 +96,7 @@ def load():
     # private test hooks (not part of include/dragposer.h)
     lib.dp_optimize_debug.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult),
                                       C.c_void_p, C.c_void_p]
-    lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f]
+    lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f, C.POINTER(C.c_uint)]
     lib.dp_debug_items.argtypes = [C.POINTER(DpModel), C.c_void_p]
     _lib = lib
     return lib

@@ -19,6 +19,7 @@ struct dp_ctx {
     float* d_bias = nullptr;
     ItemConst* d_items = nullptr;
     dp_folded folded;
+    std::vector<unsigned> smask;
     std::string err;
 };
 
@@ -172,31 +173,32 @@ static float gemm_bias(const dp_folded& f, int g, int row)
 }
 
 // host-only, exported for the CPU tests: per-wave/per-lane MFMA operand images
-//   wfrag [NWAVE][W_REGS][64], bias [2][64] (rows of c0 / b1, zero padded)
-extern "C" int dp_debug_pack(const dp_folded* f, const int* parents, float* wfrag, float* bias)
+//   wfrag [NWAVE][W_REGS][64], bias [2][64] (rows of c0 / b1, zero padded; b1 row 60 = 1 feeds the
+//   constant-1 column that carries b2), smask [NWAVE][NGEMM] (bit i: step i of the wave's chain is non-zero)
+extern "C" int dp_debug_pack(const dp_folded* f, const int* parents, float* wfrag, float* bias, unsigned* smask)
 {
-    if (!f || !parents || !wfrag || !bias) return DP_ERR_INVALID;
+    if (!f || !parents || !wfrag || !bias || !smask) return DP_ERR_INVALID;
     ItemPlan pl;
     std::string err;
     int rc = plan_items(parents, pl, err);
     if (rc != DP_OK) return fail(nullptr, rc, err);
     std::memset(wfrag, 0, sizeof(float) * NWAVE * W_REGS * 64);
+    std::memset(smask, 0, sizeof(unsigned) * NWAVE * NGEMM);
     for (int r = 0; r < 64; ++r) { bias[r] = gemm_bias(*f, G_L0, r); bias[64 + r] = gemm_bias(*f, G_L1, r); }
-    const int woff[NGEMM] = {W_OFF_L0, W_OFF_L1, W_OFF_L2A, W_OFF_B2, W_OFF_B1, W_OFF_B0};
+    bias[64 + L2_ONE_COL] = 1.0f; // lrelu(1) = 1: a1[:, 60] == 1
+    const int woff[NGEMM] = {W_OFF_L0, W_OFF_L1, W_OFF_L2, W_OFF_B2, W_OFF_B1, W_OFF_B0};
     for (int w = 0; w < NWAVE; ++w) {
         for (int g = 0; g < NGEMM; ++g) {
-            for (int slot = 0; slot < 2; ++slot) {
-                int half = 0;
-                const int tile = chunk_tile(g, w, slot, &half);
-                if (tile < 0) continue;
-                const int base = (slot == 0) ? woff[g] : W_OFF_L2B;
-                const int s0 = half ? G_HALF0[g] : 0, s1 = half ? G_NM[g] : G_HALF0[g];
-                for (int step = s0; step < s1; ++step) {
-                    for (int l = 0; l < 64; ++l) {
-                        const int row = 16 * tile + (l & 15), col = kcol(G_K[g], step, l >> 4);
-                        wfrag[(w * W_REGS + base + (step - s0)) * 64 + l] = gemm_w(*f, pl, g, row, col);
-                    }
+            const int tile = wave_tile(g, w), s0 = wave_step0(g, w), n = wave_nsteps(g, w);
+            if (tile < 0) continue;
+            for (int i = 0; i < n; ++i) {
+                bool any = false;
+                for (int l = 0; l < 64; ++l) {
+                    const float v = gemm_w(*f, pl, g, 16 * tile + (l & 15), 4 * (s0 + i) + (l >> 4));
+                    wfrag[(w * W_REGS + woff[g] + i) * 64 + l] = v;
+                    any = any || v != 0.f;
                 }
+                if (any) smask[w * NGEMM + g] |= 1u << i;
             }
         }
     }
@@ -288,8 +290,9 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     ctx->device = device;
     int rc = dp_fold_decoder(model, &ctx->folded);
     std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
+    ctx->smask.assign(NWAVE * NGEMM, 0u);
     std::vector<ItemConst> items(32);
-    if (rc == DP_OK) rc = dp_debug_pack(&ctx->folded, model->parents, wfrag.data(), bfrag.data());
+    if (rc == DP_OK) rc = dp_debug_pack(&ctx->folded, model->parents, wfrag.data(), bfrag.data(), ctx->smask.data());
     if (rc == DP_OK) rc = dp_debug_items(model, items.data());
     if (rc != DP_OK) { delete ctx; return rc; }
     int prev = 0;
@@ -336,6 +339,7 @@ static void fill_model_args(const dp_ctx* ctx, KArgs& k)
     k.wfrag = ctx->d_wfrag;
     k.bias = ctx->d_bias;
     k.items = ctx->d_items;
+    std::memcpy(k.smask, ctx->smask.data(), sizeof(k.smask));
 }
 
 static void fill_results(const dp_result* out, KArgs& k)

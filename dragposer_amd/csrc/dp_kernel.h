@@ -16,7 +16,7 @@ constexpr int DBG_STRIDE = 240;
 
 struct KArgs {
     // model (device)
-    const float* wfrag;          // [NWAVE][W_REGS][64]
+    const float* wfrag;          // [NWAVE][W_REGS][64]  per-wave, per-lane MFMA A operands
     const float* bias;           // [2][64] padded bias rows of L0 (c0) and L1 (b1)
     const dpl::ItemConst* items; // [32]
     // batch (device)
@@ -29,6 +29,7 @@ struct KArgs {
     int n_frames, n_iter, mode; // mode 0: optimise, 1: forward only (n_iter = 1)
     float lam_rot, lam_tmp, ctmp; // ctmp = 2 lam_tmp / 24
     float beta2, one_m_b1, one_m_b2, eps;
+    unsigned smask[dpl::NWAVE][dpl::NGEMM]; // bit i: step i of the wave's chain has a non-zero weight block
     AdamTab tab;
 };
 

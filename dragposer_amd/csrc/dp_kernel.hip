@@ -4,15 +4,18 @@
 // the batch (reference: DragPose.run's while loop, python/src/drag_pose.py:296-355).
 //
 // Geometry: workgroup = 512 threads (8 waves) = 16 frames; grid = ceil(B/16).
-//   * Decoder forward/backward: six products per iteration on v_mfma_f32_16x16x4_f32, weights
-//     (A operand) resident in VGPRs for the whole kernel, activations (B operand) exchanged
-//     through LDS.  Every 16-row output tile is split in two K-halves computed by two waves that
-//     share a SIMD (two independent accumulator chains per matrix pipe); the two partial planes
-//     are summed by the consumer together with the LeakyReLU / its derivative.
+//   * Decoder forward/backward: six products per iteration on v_mfma_f32_16x16x4_f32.  Output tile
+//     t (16 channels x 16 frames) belongs to wave t -- one matrix wave per SIMD -- which runs two
+//     interleaved accumulator chains (even / odd K steps), adds bias + LeakyReLU (forward) or
+//     multiplies by the LeakyReLU derivative it still holds in registers (backward) and writes ONE
+//     plane to LDS; the next product reads its B operand from there, one float per MFMA step.
+//     Forward weights live in VGPRs for the whole kernel, backward weights in LDS (fetched ahead
+//     of the barrier that precedes their use).  Structurally zero (tile, step) blocks of the
+//     folded matrices are skipped through per-wave step masks.
 //   * Kinematics phase (P3): wave w owns frames 2w,2w+1, 32 lanes per frame, one lane per joint
-//     (+1 for the root displacement); cross-joint traffic (bones, tracker gradients) goes through
-//     wave-private LDS rows, so P3 needs no workgroup barrier inside.
-//   * Adam runs redundantly in every wave on the lanes that hold z as the B operand of layer 0.
+//     (+1 for the root displacement, +1 per extra child bone); cross-joint traffic (bones, tracker
+//     gradients) goes through wave-private LDS rows, so P3 needs no workgroup barrier inside.
+//   * bL0 and Adam are fused: the two waves that produce dL/dz own z, m, v in registers.
 // 7 workgroup barriers per iteration, no global memory traffic inside the loop.
 #include <hip/hip_runtime.h>
 #include "dp_kernel.h"
@@ -43,26 +46,30 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // LDS map (floats)
-constexpr int L_A0 = 0;                            // a0p[2][16][S_A0]   (aliased by d0p)
-constexpr int L_A1 = L_A0 + 2 * FPB * S_A0;        // a1p[2][16][S_A1]   (aliased by d1p)
-constexpr int L_Y = L_A1 + 2 * FPB * S_A1;         // yp [2][16][S_Y]    (plane 0 aliased by gy)
-constexpr int L_ZERO0 = L_Y + 2 * FPB * S_Y;       // ---- everything from here on is zeroed at start
-constexpr int L_GZ = L_ZERO0;                      // gzp[2][16][S_GZ]
-constexpr int L_BONE = L_GZ + 2 * FPB * S_GZ;      // bone[16][32][4]
+constexpr int L_Z = 0;                             // zs [16][S_Z]      latent, B operand of L0
+constexpr int L_A0 = L_Z + FPB * S_Z;              // a0 [16][S_A0]     (aliased by d0)
+constexpr int L_A1 = L_A0 + FPB * S_A0;            // a1 [16][S_A1]     (aliased by d1)
+constexpr int L_GY = L_A1 + FPB * S_A1;            // gy [16][S_Y]      dL/dy quads (26 used)
+constexpr int L_Y = L_GY + FPB * S_Y;              // y  [2][16][S_Y]   plane 1: 2nd K-half of tiles 4,5 (kept for the epilogue)
+constexpr int L_ZERO0 = L_Y + FPB * S_Y;           // ---- everything from here on is zeroed at start (incl. y plane 1)
+constexpr int L_BONE = L_ZERO0 + FPB * S_Y;        // bone[16][32][4]
 constexpr int L_GPC = L_BONE + FPB * 32 * 4;       // gpc [16][24][4]  tracker position gradients by rank
 constexpr int L_CQ = L_GPC + FPB * 24 * 4;         // cq  [16][24][4]  tracker contributions to d/d(qw)
 constexpr int L_LP = L_CQ + FPB * 24 * 4;          // lp  [16][24][2]  tracker loss terms
 constexpr int L_QD = L_LP + FPB * 24 * 2;          // qd  [16][8]      qw[4], d[3]
-constexpr int L_ADM = L_QD + FPB * 8;              // adam m [2][16][S_AD]
-constexpr int L_ADV = L_ADM + 2 * FPB * S_AD;      // adam v [2][16][S_AD]
-constexpr int L_ZT = L_ADV + 2 * FPB * S_AD;       // z_tgt  [16][S_AD]
-constexpr int L_TRK = L_ZT + FPB * S_AD;           // TrackIn[16][24]
+constexpr int L_TRK = L_QD + FPB * 8;              // TrackIn[16][24]
 constexpr int L_ITEM = L_TRK + FPB * 24 * 16;      // ItemConst[32]
 constexpr int L_BIAS = L_ITEM + 32 * 32;           // bias rows of L0 (48) and L1 (64), padded to 64 each
-constexpr int WB_STRIDE = 28;                      // backward weights per lane: bL2[14] | bL1[8] | bL0[5] | pad
-constexpr int L_WB = L_BIAS + 128;                 // wb[8 waves][64 lanes][WB_STRIDE]
-constexpr int L_TOTAL = L_WB + NWAVE * 64 * WB_STRIDE;
+constexpr int L_ZT = L_BIAS + 128;                 // z_tgt [16][S_Z]
+constexpr int WB_STRIDE = 60;                      // per lane: bL2[26] pad2 | bL1[16] | bL0[10] | pad6
+constexpr int WB_B2 = 0, WB_B1 = 28, WB_B0 = 44;
+constexpr int L_ZPRE = L_ZT + FPB * S_Z;           // latent of the last forward pass [16][S_Z]
+constexpr int L_ADM = L_ZPRE + FPB * S_Z;            // Adam m [16][S_Z]   (zeroed at start: lies below L_ITEM? no -> zeroed explicitly)
+constexpr int L_ADV = L_ADM + FPB * S_Z;           // Adam v [16][S_Z]
+constexpr int L_WB = L_ADV + FPB * S_Z;            // wb[4 matrix waves][64 lanes][WB_STRIDE] backward weights
+constexpr int L_TOTAL = L_WB + 4 * 64 * WB_STRIDE;
 static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
+static_assert((WB_STRIDE % 4) == 0 && ((WB_STRIDE / 4) & 1) == 1, "16-byte rows, odd stride/4 (conflict-free b128)");
 
 DEV f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -144,28 +151,33 @@ DEV M3 mat_matT(M3 a, M3 b)
     return c;
 }
 
-// B-operand loaders: row `p` (one frame) of an LDS buffer, columns in kcol order.
-template <int K> DEV void load_row(const float* p, int h, float (&b)[K / 4])
+// B operand of steps step0 .. step0+N-1: one float per step, act[frame f16][4*step + h]
+template <int N> DEV void load_b(const float* row, int h, int step0, float (&b)[N])
 {
 #pragma unroll
-    for (int s = 0; s < K / 16; ++s) {
-        f4 v = *(const f4*)(p + 16 * s + 4 * h);
-        b[4 * s + 0] = v.x; b[4 * s + 1] = v.y; b[4 * s + 2] = v.z; b[4 * s + 3] = v.w;
-    }
-    if (K % 16 == 8) {
-        f2 v = *(const f2*)(p + (K / 16) * 16 + 2 * h);
-        b[(K / 16) * 4 + 0] = v.x; b[(K / 16) * 4 + 1] = v.y;
-    }
+    for (int i = 0; i < N; ++i) b[i] = row[4 * (step0 + i) + h];
 }
 
-template <int K> DEV void load_row_sum(const float* p0, const float* p1, int h, float (&b)[K / 4])
+// N dependent-free MFMA steps on two interleaved accumulators; bit i of `mask` (wave-uniform)
+// clear <=> the weight block of step i is structurally zero and the step is skipped
+template <int N> DEV f4 mfma_chain(const float (&w)[N], const float (&b)[N], unsigned mask, f4 acc0)
 {
-    float b0[K / 4], b1[K / 4];
-    load_row<K>(p0, h, b0);
-    load_row<K>(p1, h, b1);
+    // launder the (loop-invariant) mask: otherwise the compiler hoists every bit test out of the
+    // iteration loop into its own SGPR pair (~70 pairs), spills them, and the weights with them
+    asm volatile("" : "+s"(mask));
+    f4 acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < K / 4; ++i) b[i] = b0[i] + b1[i];
+    for (int i = 0; i < N; ++i) {
+        if ((mask >> i) & 1u) {
+            if (i & 1) acc1 = mfma4(w[i], b[i], acc1);
+            else acc0 = mfma4(w[i], b[i], acc0);
+        }
+    }
+    return acc0 + acc1;
 }
+
+DEV f4 lrelu4(f4 x) { return f4{lrelu(x.x), lrelu(x.y), lrelu(x.z), lrelu(x.w)}; }
+DEV f4 dlrelu4(f4 a, f4 g) { return f4{dlrelu(a.x, g.x), dlrelu(a.y, g.y), dlrelu(a.z, g.z), dlrelu(a.w, g.w)}; }
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
@@ -182,10 +194,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     const int nB = a.n_frames;
     const bool optimise = (a.mode == 0);
 
-    float* a0p = lds + L_A0;
-    float* a1p = lds + L_A1;
+    float* zs = lds + L_Z + f16 * S_Z;
+    float* a0r = lds + L_A0 + f16 * S_A0;       // my frame's row of a0 / d0
+    float* a1r = lds + L_A1 + f16 * S_A1;       //                   a1 / d1
+    float* yr = lds + L_Y + f16 * S_Y;          //                   y plane 0
+    const float* gyr = lds + L_GY + f16 * S_Y;  //                   gy
     float* yp = lds + L_Y;
-    float* gzp = lds + L_GZ;
     float* bone = lds + L_BONE + pf * 128;
     float* gpc = lds + L_GPC + pf * 96;
     float* cqb = lds + L_CQ + pf * 96;
@@ -193,32 +207,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     float* qdb = lds + L_QD + pf * 8;
     const ItemConst* icp = (const ItemConst*)(lds + L_ITEM) + it_id;
     const TrackIn* tin = (const TrackIn*)(lds + L_TRK) + pf * 24 + (it_id < NJ ? it_id : 23);
+    const float* wbl = lds + L_WB + ((wave & 3) * 64 + lane) * WB_STRIDE;
 
-    // ---- zero the scratch part of the LDS, copy the item table
+    // ---- zero the scratch part of the LDS (incl. plane 1 of y), copy the small tables
     for (int i = tid; i < L_ITEM - L_ZERO0; i += NTHREADS) lds[L_ZERO0 + i] = 0.f;
     for (int i = tid; i < 32 * 32; i += NTHREADS) lds[L_ITEM + i] = ((const float*)a.items)[i];
     if (tid < 128) lds[L_BIAS + tid] = a.bias[tid];
     __syncthreads();
 
-    // ---- loop-invariant MFMA A operands: forward weights stay in VGPRs for the whole kernel,
-    //      backward weights are parked in LDS (lane-major) and fetched ahead of each backward phase
-    float W[W_OFF_B2];
+    // ---- loop-invariant MFMA A operands: forward weights stay in VGPRs for the whole kernel, the
+    //      backward weights of the four matrix waves are parked in LDS (lane-major)
+    float W[W_FWD];
 #pragma unroll
-    for (int i = 0; i < W_OFF_B2; ++i) W[i] = a.wfrag[(wave * W_REGS + i) * 64 + lane];
-    float* wbl = lds + L_WB + (wave * 64 + lane) * WB_STRIDE;
-#pragma unroll
-    for (int i = 0; i < W_REGS - W_OFF_B2; ++i) wbl[i] = a.wfrag[(wave * W_REGS + W_OFF_B2 + i) * 64 + lane];
+    for (int i = 0; i < W_FWD; ++i) W[i] = a.wfrag[(wave * W_REGS + i) * 64 + lane];
+    if (wave < 4) {
+        float* wo = lds + L_WB + (wave * 64 + lane) * WB_STRIDE;
+        for (int i = 0; i < 26; ++i) wo[WB_B2 + i] = a.wfrag[(wave * W_REGS + W_OFF_B2 + i) * 64 + lane];
+        for (int i = 0; i < 16; ++i) wo[WB_B1 + i] = a.wfrag[(wave * W_REGS + W_OFF_B1 + i) * 64 + lane];
+        for (int i = 0; i < 10; ++i) wo[WB_B0 + i] = a.wfrag[(wave * W_REGS + W_OFF_B0 + i) * 64 + lane];
+    }
+    const unsigned mk_l1 = a.smask[wave][G_L1], mk_l2 = a.smask[wave][G_L2], mk_b2 = a.smask[wave][G_B2],
+                   mk_b1 = a.smask[wave][G_B1];
 
-    // ---- latent on the layer-0 B-operand lanes (every wave keeps a copy); Adam state in LDS
-    float zf[6];
-    {
+    // ---- latent, Adam state: waves 0,1 = the two output tiles of bL0; lane (f16,h) owns dims zd..zd+3
+    const int zd = 16 * (wave & 1) + 4 * h;
+    const bool zvalid = wave < 2 && zd < LAT;
+    if (zvalid) { // z, z_tgt, m, v live in LDS rows (z doubles as the B operand of L0)
         const int gf = min(blk0 + f16, nB - 1);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int col = kcol(24, i, h);
-            zf[i] = a.z0[gf * LAT + col];
-            if (optimise && wave == 0) lds[L_ZT + f16 * S_AD + col] = a.z_tgt[gf * LAT + col];
-        }
+        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        *(f4*)(zs + zd) = *(const f4*)(a.z0 + (size_t)gf * LAT + zd);
+        *(f4*)(lds + L_ZT + f16 * S_Z + zd) = optimise ? *(const f4*)(a.z_tgt + (size_t)gf * LAT + zd) : zero4;
+        *(f4*)(lds + L_ADM + f16 * S_Z + zd) = zero4;
+        *(f4*)(lds + L_ADV + f16 * S_Z + zd) = zero4;
     }
 
     // ---- P3 per-lane identity (a few integers stay in registers, the float constants are re-read from
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     // constant root-frame bones of the root's children
     if (it_id < MAX_ROOT_CH) *(f4*)(bone + icp->init_id * 4) = f4{icp->init_off[0], icp->init_off[1], icp->init_off[2], 0.f};
 
-    float a0f[10], a1f[16];
+    f4 a0v = {0.f, 0.f, 0.f, 0.f}, a1v = a0v; // my tile of a0 / a1 (kept for the LeakyReLU derivative)
     __syncthreads();
 #ifdef DP_PROFILE
     unsigned long long prof[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -270,55 +290,53 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
 
-        // ================= L0: a0 = A0 z + c0 (24 -> 40), 3 tiles x 2 K-halves on waves 0..5
-        if (wave < 6) {
-            const int t = wave % 3, hf = wave / 3;
-            f4 acc = *(const f4*)(lds + L_BIAS + 16 * t + 4 * h);
-            if (hf) acc = f4{0.f, 0.f, 0.f, 0.f};
+        // ================= L0: a0 = lrelu(A0 z + c0)   (24 -> 40), tiles on waves 0..2
+        if (wave < 3) {
+            float b[6];
+            load_b<6>(zs, h, 0, b);
+            const f4 bias = *(const f4*)(lds + L_BIAS + 16 * wave + 4 * h);
+            float w[6];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) acc = mfma4(W[W_OFF_L0 + i], hf ? zf[3 + i] : zf[i], acc);
-            *(f4*)(a0p + (hf * FPB + f16) * S_A0 + 16 * t + 4 * h) = acc;
+            for (int i = 0; i < 6; ++i) w[i] = W[W_OFF_L0 + i];
+            a0v = lrelu4(mfma_chain<6>(w, b, 0x3Fu, bias));
+            *(f4*)(a0r + 16 * wave + 4 * h) = a0v;
         }
         STAMP(0);
         __syncthreads();
         STAMP(1);
 
-        // ================= L1: a1 = A1 lrelu(a0) + b1 (40 -> 60), 4 tiles x 2 halves
-        load_row_sum<40>(a0p + f16 * S_A0, a0p + (FPB + f16) * S_A0, h, a0f);
+        // ================= L1: a1 = lrelu(A1 a0 + b1)  (40 -> 60), tiles on waves 0..3
+        if (wave < 4) {
+            float b[10];
+            load_b<10>(a0r, h, 0, b);
+            const f4 bias = *(const f4*)(lds + L_BIAS + 64 + 16 * wave + 4 * h);
+            float w[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) a0f[i] = lrelu(a0f[i]);
-        {
-            const int t = wave & 3, hf = wave >> 2;
-            f4 acc = *(const f4*)(lds + L_BIAS + 64 + 16 * t + 4 * h);
-            if (hf) acc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 5; ++i) acc = mfma4(W[W_OFF_L1 + i], hf ? a0f[5 + i] : a0f[i], acc);
-            *(f4*)(a1p + (hf * FPB + f16) * S_A1 + 16 * t + 4 * h) = acc;
+            for (int i = 0; i < 10; ++i) w[i] = W[W_OFF_L1 + i];
+            a1v = lrelu4(mfma_chain<10>(w, b, mk_l1, bias));
+            *(f4*)(a1r + 16 * wave + 4 * h) = a1v;
         }
         STAMP(2);
         __syncthreads();
         STAMP(3);
 
-        // ================= L2: y = A2 lrelu(a1) + b2 (60 -> 92), 6 tiles x 2 halves = 12 chunks
-        load_row_sum<64>(a1p + f16 * S_A1, a1p + (FPB + f16) * S_A1, h, a1f);
+        // ================= L2: y = A2 a1 + b2  (60 -> 92; b2 rides on the constant-1 column 60)
+        // tiles 0..3 on waves 0..3 (16 steps), tiles 4,5 in two K-halves on waves 4..7 (8 steps each)
+        if (wave < 4) {
+            float b[16], w[16];
+            load_b<16>(a1r, h, 0, b);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a1f[i] = lrelu(a1f[i]);
-        if (h == 3) a1f[12] = 1.f; // column 60 = kcol(64, 12, 3): constant input that carries b2
-        {
-            const int t = wave % 6, hf = wave / 6;
-            f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if (wave < 4) {
+            for (int i = 0; i < 16; ++i) w[i] = W[W_OFF_L2 + i];
+            const f4 acc = mfma_chain<16>(w, b, mk_l2, f4{0.f, 0.f, 0.f, 0.f});
+            *(f4*)(yr + 16 * wave + 4 * h) = acc;
+        } else {
+            const int half = (wave >> 1) & 1;
+            float b[8], w[8];
+            load_b<8>(a1r, h, L2_HALF_STEPS * half, b);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc0 = mfma4(W[W_OFF_L2A + i], a1f[i], acc0);
-                    acc1 = mfma4(W[W_OFF_L2B + i], a1f[8 + i], acc1);
-                }
-                *(f4*)(yp + (FPB + f16) * S_Y + 16 * (wave + 2) + 4 * h) = acc1;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc0 = mfma4(W[W_OFF_L2A + i], hf ? a1f[8 + i] : a1f[i], acc0);
-            }
-            *(f4*)(yp + (hf * FPB + f16) * S_Y + 16 * t + 4 * h) = acc0;
+            for (int i = 0; i < 8; ++i) w[i] = W[W_OFF_L2 + i];
+            const f4 acc = mfma_chain<8>(w, b, mk_l2, f4{0.f, 0.f, 0.f, 0.f});
+            *(f4*)(yr + half * FPB * S_Y + 16 * (L2_SPLIT_TILE0 + (wave & 1)) + 4 * h) = acc;
         }
         STAMP(4);
         __syncthreads();
@@ -329,14 +347,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
             if (DBG_DUMP && a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
             const f4 sd = *(const f4*)icp->sd, mu = *(const f4*)icp->mu;
-            const f4 cho = *(const f4*)icp->ch_off; // child offset (x,y,z) | ch_id
-            f4 t0, t1, t2, t3;                      // tracker inputs of my joint (tracked lanes only)
-            if (trk) {
-                t0 = *(const f4*)(tin->tp);     // tp, cgp
-                t1 = *(const f4*)(tin->tR);     // tR[0..3]
-                t2 = *(const f4*)(tin->tR + 4); // tR[4..7]
-                t3 = *(const f4*)(tin->tR + 8); // tR[8], cgr, clp, clr
-            }
             const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
             const float nn = r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z;
             const float inv = has_quat ? __builtin_amdgcn_rsqf(nn) : 0.f;
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             }
             if (is_disp) *(f4*)(qdb + 4) = f4{r.w, r.x, r.y, 0.f};
             {
+                const f4 cho = *(const f4*)icp->ch_off; // child offset (x,y,z) | ch_id
                 const V3 u = mat_vec(M, V3{cho.x, cho.y, cho.z});
                 *(f4*)(bone + ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
             }
@@ -357,6 +368,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
             const f4 qwv = *(const f4*)(qdb);
             const f4 dv = *(const f4*)(qdb + 4);
+            f4 t0, t1, t2, t3; // tracker inputs of my joint (tracked lanes only)
+            if (trk) {
+                t0 = *(const f4*)(tin->tp);     // tp, cgp
+                t1 = *(const f4*)(tin->tR);     // tR[0..3]
+                t2 = *(const f4*)(tin->tR + 4); // tR[4..7]
+                t3 = *(const f4*)(tin->tR + 8); // tR[8], cgr, clp, clr
+            }
             const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
             const M3 R0 = quat_to_mat(qw);
             V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
@@ -391,12 +409,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                 const Q4 gqw_t = quat_mat_grad(qw, C);
                 *(f4*)(gpc + rank * 4) = f4{gp.x, gp.y, gp.z, 0.f};
                 *(f4*)(cqb + rank * 4) = f4{gqw_t.w, gqw_t.x, gqw_t.y, gqw_t.z};
-                if (last) {
-                    const float l_p = t3.z * (e.x * e.x + e.y * e.y + e.z * e.z);
-                    const float l_r = t3.w * (eM.m00 * eM.m00 + eM.m01 * eM.m01 + eM.m02 * eM.m02 + eM.m10 * eM.m10 + eM.m11 * eM.m11 +
-                                              eM.m12 * eM.m12 + eM.m20 * eM.m20 + eM.m21 * eM.m21 + eM.m22 * eM.m22);
-                    *(f2*)(lpb + rank * 2) = f2{l_p, l_r};
-                }
+                const float l_p = t3.z * (e.x * e.x + e.y * e.y + e.z * e.z);
+                const float l_r = t3.w * (eM.m00 * eM.m00 + eM.m01 * eM.m01 + eM.m02 * eM.m02 + eM.m10 * eM.m10 + eM.m11 * eM.m11 +
+                                          eM.m12 * eM.m12 + eM.m20 * eM.m20 + eM.m21 * eM.m21 + eM.m22 * eM.m22);
+                *(f2*)(lpb + rank * 2) = f2{l_p, l_r}; // read by the epilogue after the last iteration
             }
             wave_sync();
             STAMP(7);
@@ -405,7 +421,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             // trackers' contributions to dL/d(qw) and (last iteration) of their loss terms
             V3 S = {0.f, 0.f, 0.f};
             Q4 gqw = {0.f, 0.f, 0.f, 0.f};
-            float lsum_p = 0.f, lsum_r = 0.f;
             {
                 unsigned m = tmask;
                 for (int e0 = 0; e0 < Emax; e0 += 6) {
@@ -415,10 +430,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                     if (is_root) {
 #pragma unroll
                         for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(cqb + (e0 + u) * 4);
-                        if (last) {
-#pragma unroll
-                            for (int u = 0; u < 6; ++u) { const f2 l = *(const f2*)(lpb + (e0 + u) * 2); lsum_p += l.x; lsum_r += l.y; }
-                        }
 #pragma unroll
                         for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
                     }
@@ -435,6 +446,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             if (is_root) { // d/d(q_0) through qw = cur (x) q_0 only
                 gq = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, gqw);
             } else { // dL/dM_j = own rotation term + S o_child^T
+                const f4 cho = *(const f4*)icp->ch_off;
                 M3 X = gM;
                 X.m00 += S.x * cho.x; X.m01 += S.x * cho.y; X.m02 += S.x * cho.z;
                 X.m10 += S.y * cho.x; X.m11 += S.y * cho.y; X.m12 += S.y * cho.z;
@@ -446,177 +458,94 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                       sd.z * (gq.y - q.y * dot) * inv, sd.w * (gq.z - q.z * dot) * inv};
             if (is_disp) gyv = f4{sd.x * S.x, sd.y * S.y, sd.z * S.z, 0.f}; // ch_sub = every joint
             if (dq >= 0) {
-                *(f4*)(yp + pf * S_Y + 4 * dq) = gyv; // gy aliases plane 0 of y
+                *(f4*)(lds + L_GY + pf * S_Y + 4 * dq) = gyv;
                 if (DBG_DUMP && a.dbg && iter == 0 && fvalid) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_GY + 4 * dq) = gyv;
-            }
-
-            // ---- outputs of the last forward pass
-            if (last && fvalid) {
-                if (is_joint) {
-                    if (a.pose) {
-                        float* o = a.pose + (size_t)gfp * 88 + 4 * it_id;
-                        o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y;
-                        o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
-                    }
-                    if (a.pos) {
-                        const V3 pw = mat_vec(R0, pr);
-                        float* o = a.pos + ((size_t)gfp * NJ + it_id) * 3;
-                        o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
-                    }
-                    if (a.rot) {
-                        const M3 G = mat_mat(R0, M);
-                        float* o = a.rot + ((size_t)gfp * NJ + it_id) * 9;
-                        o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
-                    }
-                }
-                if (is_root) {
-                    if (a.world_rot) { float* o = a.world_rot + (size_t)gfp * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
-                    if (a.loss) { a.loss[(size_t)gfp * 3 + 0] = lsum_p; a.loss[(size_t)gfp * 3 + 1] = lsum_r; }
-                }
-                if (is_disp) {
-                    if (a.disp) { float* o = a.disp + (size_t)gfp * 3; o[0] = r.w; o[1] = r.x; o[2] = r.y; }
-                    if (a.world_disp) {
-                        const V3 wd = mat_vec(R0, V3{r.w, r.x, r.y});
-                        float* o = a.world_disp + (size_t)gfp * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
-                    }
-                }
             }
         }
         if (!optimise) break; // forward-only launch (uniform)
-        float WB2[14]; // bL2 weights: issued before the barrier, landed by the time it opens
-        {
-            const f4 w0 = *(const f4*)(wbl), w1 = *(const f4*)(wbl + 4), w2 = *(const f4*)(wbl + 8);
-            const f2 w3 = *(const f2*)(wbl + 12);
-            WB2[0] = w0.x; WB2[1] = w0.y; WB2[2] = w0.z; WB2[3] = w0.w; WB2[4] = w1.x; WB2[5] = w1.y; WB2[6] = w1.z; WB2[7] = w1.w;
-            WB2[8] = w2.x; WB2[9] = w2.y; WB2[10] = w2.z; WB2[11] = w2.w; WB2[12] = w3.x; WB2[13] = w3.y;
+        float WB2[26]; // bL2 weights: issued before the barrier, landed by the time it opens
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f4 wv = *(const f4*)(wbl + WB_B2 + 4 * i);
+                WB2[4 * i] = wv.x; WB2[4 * i + 1] = wv.y; WB2[4 * i + 2] = wv.z; WB2[4 * i + 3] = wv.w;
+            }
+            const f2 wv = *(const f2*)(wbl + WB_B2 + 24);
+            WB2[24] = wv.x; WB2[25] = wv.y;
         }
         STAMP(8);
         __syncthreads();
         STAMP(9);
 
-        // ================= bL2: d1 = (A2^T gy) * lrelu'(a1)  (92(+virtual quads) -> 60), 4 tiles x 2 halves
-        {
-            const int t = wave & 3, hf = wave >> 2;
-            const float* p = yp + f16 * S_Y;
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (hf == 0) { // steps 0..11: columns 0..47
-                float b[12];
+        // ================= bL2: d1 = (A2^T gy) * lrelu'(a1)  (92 + virtual quads -> 60), tiles on waves 0..3
+        float WB1[16];
+        if (wave < 4) {
+            float b[26];
+            load_b<26>(gyr, h, 0, b);
+            const f4 acc = mfma_chain<26>(WB2, b, mk_b2, f4{0.f, 0.f, 0.f, 0.f});
+            *(f4*)(a1r + 16 * wave + 4 * h) = dlrelu4(a1v, acc); // d1 aliases a1
+            if (wave < 3) {
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const f4 v = *(const f4*)(p + 16 * s + 4 * h);
-                    b[4 * s + 0] = v.x; b[4 * s + 1] = v.y; b[4 * s + 2] = v.z; b[4 * s + 3] = v.w;
+                for (int i = 0; i < 4; ++i) {
+                    const f4 wv = *(const f4*)(wbl + WB_B1 + 4 * i);
+                    WB1[4 * i] = wv.x; WB1[4 * i + 1] = wv.y; WB1[4 * i + 2] = wv.z; WB1[4 * i + 3] = wv.w;
                 }
-#pragma unroll
-                for (int i = 0; i < 12; ++i) acc = mfma4(WB2[i], b[i], acc);
-            } else { // steps 12..25: columns 48..103
-                float b[14];
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const f4 v = *(const f4*)(p + 48 + 16 * s + 4 * h);
-                    b[4 * s + 0] = v.x; b[4 * s + 1] = v.y; b[4 * s + 2] = v.z; b[4 * s + 3] = v.w;
-                }
-                const f2 v2 = *(const f2*)(p + 96 + 2 * h);
-                b[12] = v2.x; b[13] = v2.y;
-#pragma unroll
-                for (int i = 0; i < 14; ++i) acc = mfma4(WB2[i], b[i], acc);
             }
-            *(f4*)(a1p + (hf * FPB + f16) * S_D1 + 16 * t + 4 * h) = acc; // d1p aliases a1p
-        }
-        float WB1[8];
-        {
-            const f2 w0 = *(const f2*)(wbl + 14);
-            const f4 w1 = *(const f4*)(wbl + 16);
-            const f2 w2 = *(const f2*)(wbl + 20);
-            WB1[0] = w0.x; WB1[1] = w0.y; WB1[2] = w1.x; WB1[3] = w1.y; WB1[4] = w1.z; WB1[5] = w1.w; WB1[6] = w2.x; WB1[7] = w2.y;
         }
         STAMP(10);
         __syncthreads();
         STAMP(11);
 
-        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)  (60 -> 40), 3 tiles x 2 halves on waves 0..5
-        if (wave < 6) {
-            const int t = wave % 3, hf = wave / 3;
-            float d1[16];
-            load_row_sum<64>(a1p + f16 * S_D1, a1p + (FPB + f16) * S_D1, h, d1);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) d1[i] = dlrelu(a1f[i], d1[i]);
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc = mfma4(WB1[i], hf ? d1[8 + i] : d1[i], acc);
-            *(f4*)(a0p + (hf * FPB + f16) * S_D0 + 16 * t + 4 * h) = acc; // d0p aliases a0p
-        }
-        float WB0[5];
-        {
-            const f2 w0 = *(const f2*)(wbl + 22), w1 = *(const f2*)(wbl + 24);
-            WB0[0] = w0.x; WB0[1] = w0.y; WB0[2] = w1.x; WB0[3] = w1.y; WB0[4] = wbl[26];
+        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)  (60 -> 40), tiles on waves 0..2
+        float WB0[10];
+        if (wave < 3) {
+            float b[16];
+            load_b<16>(a1r, h, 0, b);
+            const f4 acc = mfma_chain<16>(WB1, b, mk_b1, f4{0.f, 0.f, 0.f, 0.f});
+            *(f4*)(a0r + 16 * wave + 4 * h) = dlrelu4(a0v, acc); // d0 aliases a0
+            if (wave < 2) {
+                const f4 w0 = *(const f4*)(wbl + WB_B0), w1 = *(const f4*)(wbl + WB_B0 + 4);
+                const f2 w2 = *(const f2*)(wbl + WB_B0 + 8);
+                WB0[0] = w0.x; WB0[1] = w0.y; WB0[2] = w0.z; WB0[3] = w0.w; WB0[4] = w1.x; WB0[5] = w1.y; WB0[6] = w1.z; WB0[7] = w1.w;
+                WB0[8] = w2.x; WB0[9] = w2.y;
+            }
         }
         STAMP(12);
         __syncthreads();
         STAMP(13);
 
-        // ================= bL0: gz = A0^T d0  (40 -> 24), 2 tiles x 2 halves on waves 0..3
-        if (wave < 4) {
-            const int t = wave & 1, hf = wave >> 1;
-            float d0[10];
-            load_row_sum<40>(a0p + f16 * S_D0, a0p + (FPB + f16) * S_D0, h, d0);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) d0[i] = dlrelu(a0f[i], d0[i]);
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 5; ++i) acc = mfma4(WB0[i], hf ? d0[5 + i] : d0[i], acc);
-            *(f4*)(gzp + (hf * FPB + f16) * S_GZ + 16 * t + 4 * h) = acc;
+        // ================= bL0 + Adam: gz = A0^T d0 (40 -> 24) on waves 0,1, which own z, m, v of their
+        // 16 / 8 latent dims (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter+1)
+        if (wave < 2) {
+            float b[10];
+            load_b<10>(a0r, h, 0, b);
+            const f4 gz = mfma_chain<10>(WB0, b, 0x3FFu, f4{0.f, 0.f, 0.f, 0.f});
+            const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
+            f4 z4 = {0.f, 0.f, 0.f, 0.f}, zt4 = z4, m4 = z4, v4 = z4;
+            if (zvalid) {
+                z4 = *(const f4*)(zs + zd);
+                zt4 = *(const f4*)(lds + L_ZT + f16 * S_Z + zd);
+                m4 = *(const f4*)(lds + L_ADM + f16 * S_Z + zd);
+                v4 = *(const f4*)(lds + L_ADV + f16 * S_Z + zd);
+            }
+            if (last && zvalid) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = z4;
+            const f4 g = gz + a.ctmp * (z4 - zt4);
+            if (DBG_DUMP && a.dbg && iter == 0 && zvalid && blk0 + f16 < nB) *(f4*)(a.dbg + (size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + zd) = g;
+            m4 = m4 + a.one_m_b1 * (g - m4);
+            v4 = v4 * a.beta2 + a.one_m_b2 * (g * g);
+            const f4 den = f4{__builtin_amdgcn_sqrtf(v4.x), __builtin_amdgcn_sqrtf(v4.y), __builtin_amdgcn_sqrtf(v4.z),
+                              __builtin_amdgcn_sqrtf(v4.w)} * rbc2s + a.eps;
+            z4 = z4 - step * (m4 * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
+                                      __builtin_amdgcn_rcpf(den.w)});
+            if (zvalid) {
+                *(f4*)(zs + zd) = z4;
+                *(f4*)(lds + L_ADM + f16 * S_Z + zd) = m4;
+                *(f4*)(lds + L_ADV + f16 * S_Z + zd) = v4;
+            }
         }
         STAMP(14);
         __syncthreads();
         STAMP(15);
-
-        // ================= Adam on z   (torch.optim.Adam, single-tensor form)
-        // every wave updates its own register copy of z; m and v live in LDS, double-buffered:
-        // all waves read buffer iter&1, wave 0 alone writes buffer (iter+1)&1.
-        {
-            float gz[6], ztf[6], mf[6], vf[6];
-            const int rb = (iter & 1) * FPB * S_AD, wb = ((iter + 1) & 1) * FPB * S_AD;
-            load_row_sum<24>(gzp + f16 * S_GZ, gzp + (FPB + f16) * S_GZ, h, gz);
-            load_row<24>(lds + L_ZT + f16 * S_AD, h, ztf);
-            load_row<24>(lds + L_ADM + rb + f16 * S_AD, h, mf);
-            load_row<24>(lds + L_ADV + rb + f16 * S_AD, h, vf);
-            const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
-            const bool wr_out = (wave == 0) && (blk0 + f16 < nB);
-            if (last) { // uniform: outputs that live on the latent lanes
-                float lt = 0.f;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const float dz = zf[i] - ztf[i];
-                    lt += dz * dz;
-                }
-                lt += __shfl_xor(lt, 16);
-                lt += __shfl_xor(lt, 32);
-                if (wr_out) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i)
-                        if (a.z_pre) a.z_pre[(size_t)(blk0 + f16) * LAT + kcol(24, i, h)] = zf[i];
-                    if (a.loss && h == 0) a.loss[(size_t)(blk0 + f16) * 3 + 2] = lt * a.lam_tmp * (1.f / 24.f);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const float g = gz[i] + a.ctmp * (zf[i] - ztf[i]);
-                if (DBG_DUMP && a.dbg && iter == 0 && wr_out) a.dbg[(size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + kcol(24, i, h)] = g;
-                mf[i] = mf[i] + a.one_m_b1 * (g - mf[i]);
-                vf[i] = vf[i] * a.beta2 + a.one_m_b2 * g * g;
-                const float den = __builtin_amdgcn_sqrtf(vf[i]) * rbc2s + a.eps;
-                zf[i] = zf[i] - step * (mf[i] * __builtin_amdgcn_rcpf(den));
-            }
-            if (wave == 0) {
-                float* mo = lds + L_ADM + wb + f16 * S_AD;
-                float* vo = lds + L_ADV + wb + f16 * S_AD;
-                *(f4*)(mo + 4 * h) = f4{mf[0], mf[1], mf[2], mf[3]};
-                *(f2*)(mo + 16 + 2 * h) = f2{mf[4], mf[5]};
-                *(f4*)(vo + 4 * h) = f4{vf[0], vf[1], vf[2], vf[3]};
-                *(f2*)(vo + 16 + 2 * h) = f2{vf[4], vf[5]};
-            }
-        }
-        STAMP(16);
     }
 #ifdef DP_PROFILE
     if (a.dbg && tid == 0) {
@@ -625,12 +554,79 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     }
 #endif
 
-    if (optimise && wave == 0 && blk0 + f16 < nB) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (a.z) a.z[(size_t)(blk0 + f16) * LAT + kcol(24, i, h)] = zf[i];
+    // ================= epilogue: outputs of the LAST forward pass, rebuilt from what it left in LDS
+    // (y planes, qw / d, bones, tracker loss terms, the pre-step latent) -- kept out of the hot loop
+    if (!optimise) { // forward-only launch: the one forward pass ran on z itself
+        if (zvalid) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = *(const f4*)(zs + zd);
+    }
+    __syncthreads();
+    if (fvalid) {
+        const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
+        const f4 sd = *(const f4*)icp->sd, mu = *(const f4*)icp->mu;
+        const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
+        const float inv = has_quat ? __builtin_amdgcn_rsqf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z) : 0.f;
+        const Q4 q = {r.w * inv, r.x * inv, r.y * inv, r.z * inv};
+        M3 M = quat_to_mat(q);
+        if (is_root) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        const f4 qwv = *(const f4*)(qdb);
+        const f4 dv = *(const f4*)(qdb + 4);
+        const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
+        const M3 R0 = quat_to_mat(qw);
+        if (is_joint) {
+            if (a.pose) {
+                float* o = a.pose + (size_t)gfp * 88 + 4 * it_id;
+                o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y;
+                o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+            }
+            if (a.pos) {
+                V3 pr = {dv.x, dv.y, dv.z};
+                for (int i = 0; i < MAX_PATH; ++i) {
+                    const unsigned k = (i < 6) ? ((plo >> (5 * i)) & 31u) : (phi & 31u);
+                    const f4 b = *(const f4*)(bone + k * 4);
+                    pr.x += b.x; pr.y += b.y; pr.z += b.z;
+                }
+                const V3 pw = mat_vec(R0, pr);
+                float* o = a.pos + ((size_t)gfp * NJ + it_id) * 3;
+                o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+            }
+            if (a.rot) {
+                const M3 G = mat_mat(R0, M);
+                float* o = a.rot + ((size_t)gfp * NJ + it_id) * 9;
+                o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
+            }
         }
-        if (a.iters && h == 0) a.iters[blk0 + f16] = a.n_iter;
+        if (is_root) {
+            if (a.world_rot) { float* o = a.world_rot + (size_t)gfp * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
+            if (optimise) {
+                float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
+                for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(lpb + e0 * 2); lsum_p += l.x; lsum_r += l.y; }
+                const float* zrow = lds + L_ZPRE + pf * S_Z;
+                const float* ztrow = lds + L_ZT + pf * S_Z;
+                for (int k = 0; k < LAT; k += 4) {
+                    const f4 zz = *(const f4*)(zrow + k), zt = *(const f4*)(ztrow + k);
+                    if (a.z_pre) *(f4*)(a.z_pre + (size_t)gfp * LAT + k) = zz;
+                    const f4 dz = zz - zt;
+                    lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
+                }
+                if (a.loss) {
+                    a.loss[(size_t)gfp * 3 + 0] = lsum_p;
+                    a.loss[(size_t)gfp * 3 + 1] = lsum_r;
+                    a.loss[(size_t)gfp * 3 + 2] = lt * a.lam_tmp * (1.f / 24.f);
+                }
+            }
+        }
+        if (is_disp) {
+            if (a.disp) { float* o = a.disp + (size_t)gfp * 3; o[0] = r.w; o[1] = r.x; o[2] = r.y; }
+            if (a.world_disp) {
+                const V3 wd = mat_vec(R0, V3{r.w, r.x, r.y});
+                float* o = a.world_disp + (size_t)gfp * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
+            }
+        }
+    }
+
+    if (optimise && zvalid && blk0 + f16 < nB) {
+        if (a.z) *(f4*)(a.z + (size_t)(blk0 + f16) * LAT + zd) = *(const f4*)(zs + zd); // own write, same lane
+        if (a.iters && wave == 0 && h == 0) a.iters[blk0 + f16] = a.n_iter;
     }
 }
 

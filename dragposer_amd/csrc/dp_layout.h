@@ -3,14 +3,13 @@
 // code (dp_kernel.hip) so that the two cannot disagree.
 //
 // Orientation of every product: D[M=16 out-channels][N=16 frames] += A[M][K=4] * B[K=4][N]
-//   A = weights  (loop-invariant, one VGPR per MFMA, packed on the host per wave/lane)
+//   A = weights  (loop-invariant, one 32-bit register per MFMA step, packed on the host per wave/lane)
 //   B = activations of the 16 frames of the workgroup, read from LDS
 //   lane l: A[m = l&15][k = l>>4], B[k = l>>4][n = l&15], D[row = 4*(l>>4)+r][col = l&15], r=0..3
-// so a lane holds 4 consecutive output channels of ONE frame: a whole quaternion after layer 2.
-//
-// K ordering.  The dot product is order-free, so MFMA step i of a product takes, for lane
-// group h = l>>4, the column kcol(K, i, h) below: 16-column blocks are read from LDS as one
-// float4 per lane (4 steps), a trailing 8-column block as one float2 per lane (2 steps).
+// so a lane holds 4 consecutive output channels of ONE frame: a whole quaternion after layer 2,
+// and the B operand of step p is the single float  act[frame = l&15][4p + (l>>4)].
+// K runs in natural order: MFMA step p covers input channels 4p..4p+3 (= one joint of the pooled
+// skeleton), which is what makes whole (tile, step) blocks structurally zero and skippable.
 #pragma once
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
@@ -30,36 +29,37 @@ constexpr int MAX_ITERS = 256;
 
 // the six products of one iteration
 enum { G_L0 = 0, G_L1, G_L2, G_B2, G_B1, G_B0, NGEMM };
-//                      L0   L1   L2   bL2  bL1  bL0
+//                               L0  L1  L2  bL2  bL1 bL0
 constexpr int G_ROWS[NGEMM] = {40, 60, 92, 60, 40, 24};  // real output channels
 constexpr int G_KREAL[NGEMM] = {24, 40, 60, 92, 60, 40}; // real input channels
-constexpr int G_K[NGEMM] = {24, 40, 64, 104, 64, 40};    // columns read from LDS (zero padded)
-constexpr int G_NT[NGEMM] = {3, 4, 6, 4, 3, 2};          // 16-row tiles
-constexpr int G_NM[NGEMM] = {6, 10, 16, 26, 16, 10};     // MFMA steps per tile (= K/4)
-constexpr int G_HALF0[NGEMM] = {3, 5, 8, 12, 8, 5};      // steps in K-half 0 (half 1 takes the rest)
+constexpr int G_NT[NGEMM] = {3, 4, 6, 4, 3, 2};          // 16-row output tiles
+constexpr int G_NS[NGEMM] = {6, 10, 16, 26, 16, 10};     // MFMA steps over K (4 channels each)
+// Tile t of a product is computed by wave t (two interleaved accumulators: even / odd steps).
+// Exception: layer 2 has 6 tiles; tiles 4 and 5 are split in two K-halves of 8 steps over waves
+// 4..7 (wave 4+i+2*half -> tile 4+i), written to two partial planes that the reader sums.
+constexpr int L2_SPLIT_TILE0 = 4;
+constexpr int L2_HALF_STEPS = 8;
 
-// LDS row strides (floats) of the buffers; stride/4 odd keeps float4 row reads spread over banks
-constexpr int S_A0 = 52, S_A1 = 68, S_Y = 108, S_D1 = 68, S_D0 = 52, S_GZ = 36, S_AD = 28;
+// LDS row strides (floats); stride/4 odd spreads the rows of a 16-byte access over the banks
+constexpr int S_Z = 28, S_A0 = 52, S_A1 = 68, S_Y = 108;
 constexpr int L2_ONE_COL = 60; // layer-2 bias rides on a constant-1 input column (K padding 60..63)
 
-DP_HD constexpr int kcol(int K, int i, int h) {
-    return (i < (K / 16) * 4) ? 16 * (i / 4) + 4 * h + (i % 4) : (K / 16) * 16 + 2 * h + (i - (K / 16) * 4);
-}
+// per-wave weight image on the device: [L0:6][L1:10][L2:16][bL2:26][bL1:16][bL0:10]
+constexpr int W_OFF_L0 = 0, W_OFF_L1 = 6, W_OFF_L2 = 16, W_OFF_B2 = 32, W_OFF_B1 = 58, W_OFF_B0 = 74;
+constexpr int W_REGS = 84;
+constexpr int W_FWD = W_OFF_B2;          // forward weights stay in VGPRs
+constexpr int W_BWD = W_REGS - W_OFF_B2; // backward weights of waves 0..3 are parked in LDS (52 per lane)
 
-// chunk = (tile, K-half).  Wave w owns chunk slot 0 (every product) and, for L2 only, slot 1.
-// Returns tile (or -1 when the wave is idle in that product); *half receives the K-half.
-DP_HD constexpr int chunk_tile(int g, int w, int slot, int* half) {
-    int nt = G_NT[g];
-    int c = (slot == 0) ? w : w + 8;
-    if (slot == 1 && !(g == G_L2 && w < 4)) return -1;
-    if (c >= 2 * nt) return -1;
-    *half = c / nt;
-    return c % nt;
+// which (wave, product) computes which tile / step range
+DP_HD constexpr int wave_tile(int g, int w) {
+    if (g == G_L2) return w < 4 ? w : L2_SPLIT_TILE0 + (w & 1);
+    return w < G_NT[g] ? w : -1;
 }
-
-// per-wave weight registers: [L0:3][L1:5][L2 slot0:8][L2 slot1:8][bL2:14][bL1:8][bL0:5]
-constexpr int W_OFF_L0 = 0, W_OFF_L1 = 3, W_OFF_L2A = 8, W_OFF_L2B = 16, W_OFF_B2 = 24, W_OFF_B1 = 38, W_OFF_B0 = 46;
-constexpr int W_REGS = 51;
+DP_HD constexpr int wave_step0(int g, int w) { return (g == G_L2 && w >= 6) ? L2_HALF_STEPS : 0; }
+DP_HD constexpr int wave_nsteps(int g, int w) {
+    if (g == G_L2) return w < 4 ? G_NS[G_L2] : L2_HALF_STEPS;
+    return w < G_NT[g] ? G_NS[g] : 0;
+}
 
 // P3 (kinematics / loss / backward): wave w handles frames 2w, 2w+1; 32 lanes per frame; one
 // item per lane.  Every item reads one 4-channel quad of y, handles at most ONE child bone and

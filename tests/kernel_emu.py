@@ -11,14 +11,10 @@ import numpy as np
 
 from dragposer_amd import _lib
 
-NWAVE, W_REGS = 8, 51
-W_OFF = dict(L0=0, L1=3, L2A=8, L2B=16, B2=24, B1=38, B0=46)
+NWAVE, W_REGS, NGEMM = 8, 84, 6
+W_OFF = dict(L0=0, L1=6, L2=16, B2=32, B1=58, B0=74)
+G_L0, G_L1, G_L2, G_B2, G_B1, G_B0 = range(6)
 S_Y = 108
-
-
-def kcol(K, i, h):
-    nb = (K // 16) * 4
-    return 16 * (i // 4) + 4 * h + (i % 4) if i < nb else (K // 16) * 16 + 2 * h + (i - nb)
 
 
 ITEM_DT = np.dtype([("sd", "f4", 4), ("mu", "f4", 4), ("ch_off", "f4", 3), ("ch_id", "i4"), ("ch_sub", "u4"),
@@ -32,13 +28,15 @@ def host_tables(host_model):
     _, folded = host_model.fold()
     wfrag = np.zeros((NWAVE, W_REGS, 64), np.float32)
     bias = np.zeros((2, 64), np.float32)
+    smask = np.zeros((NWAVE, NGEMM), np.uint32)
     rc = lib.dp_debug_pack(C.byref(folded), host_model.parents.ctypes.data_as(C.POINTER(C.c_int)),
-                           wfrag.ctypes.data_as(C.POINTER(C.c_float)), bias.ctypes.data_as(C.POINTER(C.c_float)))
+                           wfrag.ctypes.data_as(C.POINTER(C.c_float)), bias.ctypes.data_as(C.POINTER(C.c_float)),
+                           smask.ctypes.data_as(C.POINTER(C.c_uint)))
     assert rc == 0, _lib.last_error()
     items = np.zeros(32, ITEM_DT)
     rc = lib.dp_debug_items(C.byref(host_model.struct), items.ctypes.data_as(C.c_void_p))
     assert rc == 0, _lib.last_error()
-    return wfrag, bias, items
+    return wfrag, bias, items, smask
 
 
 def mfma(a, b, acc):
@@ -53,13 +51,35 @@ def mfma(a, b, acc):
     return out
 
 
-def load_row(buf_rows, K):
-    """B-operand fragments of all 64 lanes: buf_rows [16][stride] -> [K/4][64]."""
-    out = np.zeros((K // 4, 64))
+def load_b(buf_rows, step0, n):
+    """B-operand floats of all 64 lanes for steps step0..step0+n-1: act[frame l&15][4*step + (l>>4)]."""
+    out = np.zeros((n, 64))
     for l in range(64):
-        f, h = l & 15, l >> 4
-        for i in range(K // 4):
-            out[i, l] = buf_rows[f, kcol(K, i, h)]
+        for i in range(n):
+            out[i, l] = buf_rows[l & 15, 4 * (step0 + i) + (l >> 4)]
+    return out
+
+
+def chain(wf, wave, off, b, mask, acc0=None):
+    """two interleaved accumulators, masked steps (kernel: mfma_chain)."""
+    acc = [np.zeros((64, 4)) if acc0 is None else acc0.copy(), np.zeros((64, 4))]
+    for i in range(b.shape[0]):
+        if (int(mask) >> i) & 1:
+            acc[i & 1] = mfma(wf[wave, off + i], b[i], acc[i & 1])
+        else:
+            assert not np.any(wf[wave, off + i]), "masked step must have zero weights"
+    return acc[0] + acc[1]
+
+
+def store_tile(buf_rows, tile, acc):
+    for l in range(64):
+        buf_rows[l & 15, 16 * tile + 4 * (l >> 4): 16 * tile + 4 * (l >> 4) + 4] = acc[l]
+
+
+def bias_frag(bias_row, tile):
+    out = np.zeros((64, 4))
+    for l in range(64):
+        out[l] = bias_row[16 * tile + 4 * (l >> 4): 16 * tile + 4 * (l >> 4) + 4]
     return out
 
 
@@ -93,54 +113,30 @@ def quat_mul(a, b):
 
 def emulate_iteration(tables, z, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, lam_rot, lam_tmp):
     """One decode -> P3 -> backward for 16 frames.  Returns y[16,104], gy[16,104], gz[16,24], loss[16,2]."""
-    wfrag, bias, items = tables
+    wfrag, bias, items, smask = tables
     wf = wfrag.astype(np.float64)
     z = np.asarray(z, np.float64)
     zrows = np.zeros((16, 28)); zrows[:, :24] = z
-    zf = load_row(zrows, 24)
-    # ---- L0
-    a0p = np.zeros((2, 16, 52))
-    for wv in range(6):
-        t, hf = wv % 3, wv // 3
-        acc = np.zeros((64, 4))
-        if hf == 0:
-            for l in range(64):
-                acc[l] = bias[0, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4]
-        for i in range(3):
-            acc = mfma(wf[wv, W_OFF["L0"] + i], zf[3 * hf + i], acc)
-        for l in range(64):
-            a0p[hf, l & 15, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4] = acc[l]
-    a0f = lrelu(load_row(a0p[0], 40) + load_row(a0p[1], 40))
-    # ---- L1
-    a1p = np.zeros((2, 16, 68))
-    for wv in range(8):
-        t, hf = wv & 3, wv >> 2
-        acc = np.zeros((64, 4))
-        if hf == 0:
-            for l in range(64):
-                acc[l] = bias[1, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4]
-        for i in range(5):
-            acc = mfma(wf[wv, W_OFF["L1"] + i], a0f[5 * hf + i], acc)
-        for l in range(64):
-            a1p[hf, l & 15, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4] = acc[l]
-    a1f = lrelu(load_row(a1p[0], 64) + load_row(a1p[1], 64))
-    a1f[12, 48:64] = 1.0  # lanes h == 3: constant-1 column 60
-    # ---- L2
-    yp = np.full((2, 16, S_Y), np.nan)
-    for wv in range(8):
-        t, hf = wv % 6, wv // 6
-        acc0 = np.zeros((64, 4)); acc1 = np.zeros((64, 4))
-        for i in range(8):
-            acc0 = mfma(wf[wv, W_OFF["L2A"] + i], a1f[8 * hf + i], acc0)
-            if wv < 4:
-                acc1 = mfma(wf[wv, W_OFF["L2B"] + i], a1f[8 + i], acc1)
-        for l in range(64):
-            yp[hf, l & 15, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4] = acc0[l]
-            if wv < 4:
-                yp[1, l & 15, 16 * (wv + 2) + 4 * (l >> 4): 16 * (wv + 2) + 4 * (l >> 4) + 4] = acc1[l]
+    # ---- L0 (waves 0..2), L1 (waves 0..3): bias + LeakyReLU in the producer
+    a0 = np.zeros((16, 52)); a0v = {}
+    for wv in range(3):
+        a0v[wv] = lrelu(chain(wf, wv, W_OFF["L0"], load_b(zrows, 0, 6), 0x3F, bias_frag(bias[0], wv)))
+        store_tile(a0, wv, a0v[wv])
+    a1 = np.zeros((16, 68)); a1v = {}
+    for wv in range(4):
+        a1v[wv] = lrelu(chain(wf, wv, W_OFF["L1"], load_b(a0, 0, 10), smask[wv, G_L1], bias_frag(bias[1], wv)))
+        store_tile(a1, wv, a1v[wv])
+    assert np.all(a1[:, 60] == 1.0)
+    # ---- L2: tiles 0..3 on waves 0..3, tiles 4,5 in two K-halves on waves 4..7 (two planes)
+    yp = np.zeros((2, 16, S_Y))
+    for wv in range(4):
+        store_tile(yp[0], wv, chain(wf, wv, W_OFF["L2"], load_b(a1, 0, 16), smask[wv, G_L2]))
+    for wv in range(4, 8):
+        half = (wv >> 1) & 1
+        store_tile(yp[half], 4 + (wv & 1), chain(wf, wv, W_OFF["L2"], load_b(a1, 8 * half, 8), smask[wv, G_L2]))
     ysum = yp[0] + yp[1]
     # ---- P3 per frame, per item
-    gy = yp[0].copy()  # aliasing: gy overwrites plane 0
+    gy = np.zeros((16, S_Y))
     loss = np.zeros((16, 2))
     for f in range(16):
         trk = np.asarray(tracked[f]) != 0
@@ -172,14 +168,12 @@ def emulate_iteration(tables, z, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, l
         qw, d = qd[:4], qd[4:7]
         R0 = quat_to_mat(qw)
         gM = {it: np.zeros((3, 3)) for it in range(32)}
-        pr = {}
         for it in range(32):
             ic = items[it]
             p = d.copy()
             for i in range(7):
                 k = (int(ic["path_lo"]) >> (5 * i)) & 31 if i < 6 else int(ic["path_hi"]) & 31
                 p = p + bone[k, :3]
-            pr[it] = p
             if it < 22 and trk[it]:
                 tp, tR = tgt_pos[f, it].astype(np.float64), tgt_rot[f, it].reshape(3, 3).astype(np.float64)
                 clp, clr = w[f, it, 0] / (3 * E), lam_rot * w[f, it, 1] / (9 * E)
@@ -209,44 +203,17 @@ def emulate_iteration(tables, z, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, l
                 gyv = np.array([ic["sd"][0] * S[0], ic["sd"][1] * S[1], ic["sd"][2] * S[2], 0.0])
             if ic["dst_quad"] >= 0:
                 gy[f, 4 * ic["dst_quad"]: 4 * ic["dst_quad"] + 4] = gyv
-    assert not np.isnan(gy[:, :104]).any()
-    # ---- bL2
-    d1p = np.zeros((2, 16, 68))
-    gyf = load_row(gy, 104)
-    for wv in range(8):
-        t, hf = wv & 3, wv >> 2
-        acc = np.zeros((64, 4))
-        steps = range(0, 12) if hf == 0 else range(12, 26)
-        for n, i in enumerate(steps):
-            acc = mfma(wf[wv, W_OFF["B2"] + n], gyf[i], acc)
-        for l in range(64):
-            d1p[hf, l & 15, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4] = acc[l]
-    d1 = load_row(d1p[0], 64) + load_row(d1p[1], 64)
-    d1 = np.where(a1f > 0, d1, 0.2 * d1)
-    # ---- bL1
-    d0p = np.zeros((2, 16, 52))
-    for wv in range(6):
-        t, hf = wv % 3, wv // 3
-        acc = np.zeros((64, 4))
-        for i in range(8):
-            acc = mfma(wf[wv, W_OFF["B1"] + i], d1[8 * hf + i], acc)
-        for l in range(64):
-            d0p[hf, l & 15, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4] = acc[l]
-    d0 = load_row(d0p[0], 40) + load_row(d0p[1], 40)
-    d0 = np.where(a0f > 0, d0, 0.2 * d0)
-    # ---- bL0
-    gzp = np.zeros((2, 16, 36))
+    # ---- backward products: mask by the producer's own activations
+    d1 = np.zeros((16, 68))
     for wv in range(4):
-        t, hf = wv & 1, wv >> 1
-        acc = np.zeros((64, 4))
-        for i in range(5):
-            acc = mfma(wf[wv, W_OFF["B0"] + i], d0[5 * hf + i], acc)
-        for l in range(64):
-            gzp[hf, l & 15, 16 * t + 4 * (l >> 4): 16 * t + 4 * (l >> 4) + 4] = acc[l]
-    gzf = load_row(gzp[0], 24) + load_row(gzp[1], 24)
-    gz = np.zeros((16, 24))
-    for l in range(64):
-        for i in range(6):
-            gz[l & 15, kcol(24, i, l >> 4)] = gzf[i, l]
-    gz += 2 * lam_tmp * (z - np.asarray(z_tgt, np.float64)) / 24
+        acc = chain(wf, wv, W_OFF["B2"], load_b(gy, 0, 26), smask[wv, G_B2])
+        store_tile(d1, wv, np.where(a1v[wv] > 0, acc, 0.2 * acc))
+    d0 = np.zeros((16, 52))
+    for wv in range(3):
+        acc = chain(wf, wv, W_OFF["B1"], load_b(d1, 0, 16), smask[wv, G_B1])
+        store_tile(d0, wv, np.where(a0v[wv] > 0, acc, 0.2 * acc))
+    gzr = np.zeros((16, 36))
+    for wv in range(2):
+        store_tile(gzr, wv, chain(wf, wv, W_OFF["B0"], load_b(d0, 0, 10), 0x3FF))
+    gz = gzr[:, :24] + 2 * lam_tmp * (z - np.asarray(z_tgt, np.float64)) / 24
     return ysum[:, :104], gy[:, :104], gz, loss
