@@ -56,10 +56,10 @@ constexpr int L_BONE = L_ZERO0 + FPB * S_Y;        // bone[16][32][4]
 constexpr int L_GPC = L_BONE + FPB * 32 * 4;       // gpc [16][24][4]  tracker position gradients by rank
 constexpr int L_CQ = L_GPC + FPB * 24 * 4;         // cq  [16][24][4]  tracker contributions to d/d(qw)
 constexpr int L_LP = L_CQ + FPB * 24 * 4;          // lp  [16][24][2]  tracker loss terms
-constexpr int L_QD = L_LP + FPB * 24 * 2;          // qd  [16][8]      qw[4], d[3]
-constexpr int L_TRK = L_QD + FPB * 8;              // TrackIn[16][24]
-constexpr int L_ITEM = L_TRK + FPB * 24 * 16;      // ItemConst[32]
-constexpr int L_BIAS = L_ITEM + 32 * 32;           // bias rows of L0 (48) and L1 (64), padded to 64 each
+constexpr int L_QD = L_LP + FPB * 24 * 2;          // qd  [16][20]     qw[4] | d[3],0 | R0 rows (3 x [3],0)
+constexpr int L_TRK = L_QD + FPB * 20;             // tracker inputs, SoA: [16 frames][4 quads][24 joints][4]
+constexpr int L_ITEM = L_TRK + FPB * 24 * 16;      // item constants, SoA: sd[32][4] | mu[32][4] | child offset[32][4]
+constexpr int L_BIAS = L_ITEM + 3 * 32 * 4;        // bias rows of L0 (48) and L1 (64), padded to 64 each
 constexpr int L_ZT = L_BIAS + 128;                 // z_tgt [16][S_Z]
 constexpr int WB_STRIDE = 60;                      // per lane: bL2[26] pad2 | bL1[16] | bL0[10] | pad6
 constexpr int WB_B2 = 0, WB_B1 = 28, WB_B0 = 44;
@@ -176,6 +176,12 @@ template <int N> DEV f4 mfma_chain(const float (&w)[N], const float (&b)[N], uns
     return acc0 + acc1;
 }
 
+// Bank swizzle of the B-operand buffers: a row is 16-byte aligned, so rows f and f+8 start on the same
+// ds_read_b32 bank and the 32 lanes (16 frames x 2 K-groups) of a B read would pair up two by two.  Frames
+// 8..15 therefore keep every 4-channel quad rotated by two floats: writers store swz4(v), the B read uses
+// K-group h^2.  (Involution; P3 / epilogue readers of a quad apply swz4 again.)
+DEV f4 swz4(f4 v, bool hi) { return hi ? f4{v.z, v.w, v.x, v.y} : v; }
+
 DEV f4 lrelu4(f4 x) { return f4{lrelu(x.x), lrelu(x.y), lrelu(x.z), lrelu(x.w)}; }
 DEV f4 dlrelu4(f4 a, f4 g) { return f4{dlrelu(a.x, g.x), dlrelu(a.y, g.y), dlrelu(a.z, g.z), dlrelu(a.w, g.w)}; }
 
@@ -188,6 +194,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f16 = lane & 15, h = lane >> 4;   // MFMA roles: frame column, K / row group
+    const bool fhi = f16 >= 8;                  // swizzled row (see swz4)
+    const int hs = h ^ (fhi ? 2 : 0);           // K-group as laid out in my frame's row
     const int pf = 2 * wave + (lane >> 5);      // P3 roles: frame (row of every LDS buffer)
     const int it_id = lane & 31;                //           item id
     const int blk0 = blockIdx.x * FPB;
@@ -204,14 +212,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     float* gpc = lds + L_GPC + pf * 96;
     float* cqb = lds + L_CQ + pf * 96;
     float* lpb = lds + L_LP + pf * 48;
-    float* qdb = lds + L_QD + pf * 8;
-    const ItemConst* icp = (const ItemConst*)(lds + L_ITEM) + it_id;
-    const TrackIn* tin = (const TrackIn*)(lds + L_TRK) + pf * 24 + (it_id < NJ ? it_id : 23);
+    float* qdb = lds + L_QD + pf * 20;
+    const ItemConst* icg = a.items + it_id;                       // global copy: read once, before the loop
+    const float* icl = lds + L_ITEM + 4 * it_id;                  // LDS copy (SoA): sd, +128: mu, +256: child offset
+    const float* tin = lds + L_TRK + (pf * 96 + (it_id < NJ ? it_id : 23)) * 4; // + 96*k floats: k-th quad of TrackIn
     const float* wbl = lds + L_WB + ((wave & 3) * 64 + lane) * WB_STRIDE;
 
     // ---- zero the scratch part of the LDS (incl. plane 1 of y), copy the small tables
     for (int i = tid; i < L_ITEM - L_ZERO0; i += NTHREADS) lds[L_ZERO0 + i] = 0.f;
-    for (int i = tid; i < 32 * 32; i += NTHREADS) lds[L_ITEM + i] = ((const float*)a.items)[i];
+    if (tid < 32 * 3) { // item constants: AoS (128 B per item, bank-conflicting) -> three float4 planes
+        const int it = tid & 31, k = tid >> 5;
+        const float* src = (const float*)(a.items + it) + (k == 0 ? 0 : k == 1 ? 4 : 8);
+        *(f4*)(lds + L_ITEM + k * 128 + 4 * it) = f4{src[0], src[1], src[2], k == 2 ? 0.f : src[3]};
+    }
     if (tid < 128) lds[L_BIAS + tid] = a.bias[tid];
     __syncthreads();
 
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     if (zvalid) { // z, z_tgt, m, v live in LDS rows (z doubles as the B operand of L0)
         const int gf = min(blk0 + f16, nB - 1);
         const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        *(f4*)(zs + zd) = *(const f4*)(a.z0 + (size_t)gf * LAT + zd);
+        *(f4*)(zs + zd) = swz4(*(const f4*)(a.z0 + (size_t)gf * LAT + zd), fhi);
         *(f4*)(lds + L_ZT + f16 * S_Z + zd) = optimise ? *(const f4*)(a.z_tgt + (size_t)gf * LAT + zd) : zero4;
         *(f4*)(lds + L_ADM + f16 * S_Z + zd) = zero4;
         *(f4*)(lds + L_ADV + f16 * S_Z + zd) = zero4;
@@ -243,10 +256,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
     // ---- P3 per-lane identity (a few integers stay in registers, the float constants are re-read from
     //      LDS every iteration to keep the register budget for the kinematics temporaries)
-    const int sq = icp->src_quad, dq = icp->dst_quad;
-    const int ch_id = icp->ch_id;
-    const unsigned ch_sub = icp->ch_sub, plo = icp->path_lo, phi = icp->path_hi;
-    const int kind = icp->kind;
+    const int sq = icg->src_quad, dq = icg->dst_quad;
+    const int ch_id = icg->ch_id;
+    const unsigned ch_sub = icg->ch_sub, plo = icg->path_lo, phi = icg->path_hi;
+    const int kind = icg->kind;
     const bool is_joint = kind == KIND_JOINT || kind == KIND_ROOT; // owns a tracker slot / outputs
     const bool has_quat = kind != KIND_DISP && kind != KIND_IDLE;
     const bool is_root = kind == KIND_ROOT;
@@ -262,23 +275,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     const int E = __popc(tmask);
     const int rank = __popc(tmask & ((1u << it_id) - 1u));
     const int Emax = max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 32));
+    unsigned sel6 = 0; // bit u: the tracked joint of rank u lies below my child bone (first 6 ranks, loop-invariant)
+    {
+        unsigned m = tmask;
+        for (int u = 0; u < 6; ++u) {
+            const int t = __builtin_ctz(m | 0x80000000u);
+            m &= m - 1u;
+            sel6 |= ((ch_sub >> t) & 1u) << u;
+        }
+    }
     if (trk) {
         const float invE = 1.f / (float)E;
         const float* p = a.tgt_pos + (size_t)(gfc * NJ + it_id) * 3;
         const float* r = a.tgt_rot + (size_t)(gfc * NJ + it_id) * 9;
         const float wp = a.w[(gfc * NJ + it_id) * 2 + 0], wr = a.w[(gfc * NJ + it_id) * 2 + 1];
-        TrackIn t;
-        t.tp[0] = p[0]; t.tp[1] = p[1]; t.tp[2] = p[2];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) t.tR[i] = r[i];
-        t.clp = wp * invE * (1.f / 3.f);             // loss_pos coefficient  w_pos / (3E)
-        t.clr = a.lam_rot * wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
-        t.cgp = 2.f * t.clp;
-        t.cgr = 2.f * t.clr;
-        *(TrackIn*)(lds + L_TRK + (pf * 24 + it_id) * 16) = t;
+        const float clp = wp * invE * (1.f / 3.f);             // loss_pos coefficient  w_pos / (3E)
+        const float clr = a.lam_rot * wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
+        float* t = lds + L_TRK + (pf * 96 + it_id) * 4;        // TrackIn as four float4 planes (SoA)
+        *(f4*)(t) = f4{p[0], p[1], p[2], 2.f * clp};
+        *(f4*)(t + 96) = f4{r[0], r[1], r[2], r[3]};
+        *(f4*)(t + 192) = f4{r[4], r[5], r[6], r[7]};
+        *(f4*)(t + 288) = f4{r[8], 2.f * clr, clp, clr};
     }
     // constant root-frame bones of the root's children
-    if (it_id < MAX_ROOT_CH) *(f4*)(bone + icp->init_id * 4) = f4{icp->init_off[0], icp->init_off[1], icp->init_off[2], 0.f};
+    if (it_id < MAX_ROOT_CH) *(f4*)(bone + icg->init_id * 4) = f4{icg->init_off[0], icg->init_off[1], icg->init_off[2], 0.f};
 
     f4 a0v = {0.f, 0.f, 0.f, 0.f}, a1v = a0v; // my tile of a0 / a1 (kept for the LeakyReLU derivative)
     __syncthreads();
@@ -293,13 +313,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         // ================= L0: a0 = lrelu(A0 z + c0)   (24 -> 40), tiles on waves 0..2
         if (wave < 3) {
             float b[6];
-            load_b<6>(zs, h, 0, b);
+            load_b<6>(zs, hs, 0, b);
             const f4 bias = *(const f4*)(lds + L_BIAS + 16 * wave + 4 * h);
             float w[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) w[i] = W[W_OFF_L0 + i];
             a0v = lrelu4(mfma_chain<6>(w, b, 0x3Fu, bias));
-            *(f4*)(a0r + 16 * wave + 4 * h) = a0v;
+            *(f4*)(a0r + 16 * wave + 4 * h) = swz4(a0v, fhi);
         }
         STAMP(0);
         __syncthreads();
@@ -308,13 +328,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         // ================= L1: a1 = lrelu(A1 a0 + b1)  (40 -> 60), tiles on waves 0..3
         if (wave < 4) {
             float b[10];
-            load_b<10>(a0r, h, 0, b);
+            load_b<10>(a0r, hs, 0, b);
             const f4 bias = *(const f4*)(lds + L_BIAS + 64 + 16 * wave + 4 * h);
             float w[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) w[i] = W[W_OFF_L1 + i];
             a1v = lrelu4(mfma_chain<10>(w, b, mk_l1, bias));
-            *(f4*)(a1r + 16 * wave + 4 * h) = a1v;
+            *(f4*)(a1r + 16 * wave + 4 * h) = swz4(a1v, fhi);
         }
         STAMP(2);
         __syncthreads();
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         // tiles 0..3 on waves 0..3 (16 steps), tiles 4,5 in two K-halves on waves 4..7 (8 steps each)
         if (wave < 4) {
             float b[16], w[16];
-            load_b<16>(a1r, h, 0, b);
+            load_b<16>(a1r, hs, 0, b);
 #pragma unroll
             for (int i = 0; i < 16; ++i) w[i] = W[W_OFF_L2 + i];
             const f4 acc = mfma_chain<16>(w, b, mk_l2, f4{0.f, 0.f, 0.f, 0.f});
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         } else {
             const int half = (wave >> 1) & 1;
             float b[8], w[8];
-            load_b<8>(a1r, h, L2_HALF_STEPS * half, b);
+            load_b<8>(a1r, hs, L2_HALF_STEPS * half, b);
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = W[W_OFF_L2 + i];
             const f4 acc = mfma_chain<8>(w, b, mk_l2, f4{0.f, 0.f, 0.f, 0.f});
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         {
             const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
             if (DBG_DUMP && a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
-            const f4 sd = *(const f4*)icp->sd, mu = *(const f4*)icp->mu;
+            const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
             const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
             const float nn = r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z;
             const float inv = has_quat ? __builtin_amdgcn_rsqf(nn) : 0.f;
@@ -354,12 +374,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             M3 M = quat_to_mat(q);
             if (is_root) {
                 const Q4 qw0 = quat_mul(cur, q);
+                const M3 R = quat_to_mat(qw0); // world root rotation, computed once per frame
                 *(f4*)(qdb) = f4{qw0.w, qw0.x, qw0.y, qw0.z};
+                *(f4*)(qdb + 8) = f4{R.m00, R.m01, R.m02, 0.f};
+                *(f4*)(qdb + 12) = f4{R.m10, R.m11, R.m12, 0.f};
+                *(f4*)(qdb + 16) = f4{R.m20, R.m21, R.m22, 0.f};
                 M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
             }
             if (is_disp) *(f4*)(qdb + 4) = f4{r.w, r.x, r.y, 0.f};
             {
-                const f4 cho = *(const f4*)icp->ch_off; // child offset (x,y,z) | ch_id
+                const f4 cho = *(const f4*)(icl + 256); // child offset (x,y,z)
                 const V3 u = mat_vec(M, V3{cho.x, cho.y, cho.z});
                 *(f4*)(bone + ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
             }
@@ -368,15 +392,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
             const f4 qwv = *(const f4*)(qdb);
             const f4 dv = *(const f4*)(qdb + 4);
+            const f4 r0v = *(const f4*)(qdb + 8), r1v = *(const f4*)(qdb + 12), r2v = *(const f4*)(qdb + 16);
             f4 t0, t1, t2, t3; // tracker inputs of my joint (tracked lanes only)
             if (trk) {
-                t0 = *(const f4*)(tin->tp);     // tp, cgp
-                t1 = *(const f4*)(tin->tR);     // tR[0..3]
-                t2 = *(const f4*)(tin->tR + 4); // tR[4..7]
-                t3 = *(const f4*)(tin->tR + 8); // tR[8], cgr, clp, clr
+                t0 = *(const f4*)(tin);       // tp, cgp
+                t1 = *(const f4*)(tin + 96);  // tR[0..3]
+                t2 = *(const f4*)(tin + 192); // tR[4..7]
+                t3 = *(const f4*)(tin + 288); // tR[8], cgr, clp, clr
             }
             const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
-            const M3 R0 = quat_to_mat(qw);
+            const M3 R0 = {r0v.x, r0v.y, r0v.z, r1v.x, r1v.y, r1v.z, r2v.x, r2v.y, r2v.z};
             V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
             {
                 f4 b[MAX_PATH];
@@ -422,23 +447,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             V3 S = {0.f, 0.f, 0.f};
             Q4 gqw = {0.f, 0.f, 0.f, 0.f};
             {
-                unsigned m = tmask;
-                for (int e0 = 0; e0 < Emax; e0 += 6) {
-                    f4 g[6], c[6];
+                f4 g[6], c[6];
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(gpc + (e0 + u) * 4);
-                    if (is_root) {
+                for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(gpc + u * 4);
+                if (is_root) {
 #pragma unroll
-                        for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(cqb + (e0 + u) * 4);
+                    for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(cqb + u * 4);
 #pragma unroll
-                        for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
-                    }
+                    for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
+                }
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) {
+                for (int u = 0; u < 6; ++u) {
+                    const float b = (float)((sel6 >> u) & 1u);
+                    S.x += b * g[u].x; S.y += b * g[u].y; S.z += b * g[u].z;
+                }
+                if (Emax > 6) { // more than 6 trackers in a frame of this wave (uniform, rare): general path
+                    unsigned m = tmask;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) m &= m - 1u;
+                    for (int e0 = 6; e0 < Emax; ++e0) {
+                        const f4 ge = *(const f4*)(gpc + e0 * 4);
                         const int t = __builtin_ctz(m | 0x80000000u); // joint id of this rank (31 when exhausted)
                         m &= m - 1u;
                         const float b = (float)((ch_sub >> t) & 1u);
-                        S.x += b * g[u].x; S.y += b * g[u].y; S.z += b * g[u].z;
+                        S.x += b * ge.x; S.y += b * ge.y; S.z += b * ge.z;
+                        if (is_root) { const f4 ce = *(const f4*)(cqb + e0 * 4); gqw.w += ce.x; gqw.x += ce.y; gqw.y += ce.z; gqw.z += ce.w; }
                     }
                 }
             }
@@ -446,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             if (is_root) { // d/d(q_0) through qw = cur (x) q_0 only
                 gq = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, gqw);
             } else { // dL/dM_j = own rotation term + S o_child^T
-                const f4 cho = *(const f4*)icp->ch_off;
+                const f4 cho = *(const f4*)(icl + 256);
                 M3 X = gM;
                 X.m00 += S.x * cho.x; X.m01 += S.x * cho.y; X.m02 += S.x * cho.z;
                 X.m10 += S.y * cho.x; X.m11 += S.y * cho.y; X.m12 += S.y * cho.z;
@@ -458,7 +491,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                       sd.z * (gq.y - q.y * dot) * inv, sd.w * (gq.z - q.z * dot) * inv};
             if (is_disp) gyv = f4{sd.x * S.x, sd.y * S.y, sd.z * S.z, 0.f}; // ch_sub = every joint
             if (dq >= 0) {
-                *(f4*)(lds + L_GY + pf * S_Y + 4 * dq) = gyv;
+                *(f4*)(lds + L_GY + pf * S_Y + 4 * dq) = swz4(gyv, pf >= 8);
                 if (DBG_DUMP && a.dbg && iter == 0 && fvalid) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_GY + 4 * dq) = gyv;
             }
         }
@@ -481,9 +514,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         float WB1[16];
         if (wave < 4) {
             float b[26];
-            load_b<26>(gyr, h, 0, b);
+            load_b<26>(gyr, hs, 0, b);
             const f4 acc = mfma_chain<26>(WB2, b, mk_b2, f4{0.f, 0.f, 0.f, 0.f});
-            *(f4*)(a1r + 16 * wave + 4 * h) = dlrelu4(a1v, acc); // d1 aliases a1
+            *(f4*)(a1r + 16 * wave + 4 * h) = swz4(dlrelu4(a1v, acc), fhi); // d1 aliases a1
             if (wave < 3) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -500,9 +533,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         float WB0[10];
         if (wave < 3) {
             float b[16];
-            load_b<16>(a1r, h, 0, b);
+            load_b<16>(a1r, hs, 0, b);
             const f4 acc = mfma_chain<16>(WB1, b, mk_b1, f4{0.f, 0.f, 0.f, 0.f});
-            *(f4*)(a0r + 16 * wave + 4 * h) = dlrelu4(a0v, acc); // d0 aliases a0
+            *(f4*)(a0r + 16 * wave + 4 * h) = swz4(dlrelu4(a0v, acc), fhi); // d0 aliases a0
             if (wave < 2) {
                 const f4 w0 = *(const f4*)(wbl + WB_B0), w1 = *(const f4*)(wbl + WB_B0 + 4);
                 const f2 w2 = *(const f2*)(wbl + WB_B0 + 8);
@@ -518,12 +551,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         // 16 / 8 latent dims (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter+1)
         if (wave < 2) {
             float b[10];
-            load_b<10>(a0r, h, 0, b);
+            load_b<10>(a0r, hs, 0, b);
             const f4 gz = mfma_chain<10>(WB0, b, 0x3FFu, f4{0.f, 0.f, 0.f, 0.f});
             const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
             f4 z4 = {0.f, 0.f, 0.f, 0.f}, zt4 = z4, m4 = z4, v4 = z4;
             if (zvalid) {
-                z4 = *(const f4*)(zs + zd);
+                z4 = swz4(*(const f4*)(zs + zd), fhi);
                 zt4 = *(const f4*)(lds + L_ZT + f16 * S_Z + zd);
                 m4 = *(const f4*)(lds + L_ADM + f16 * S_Z + zd);
                 v4 = *(const f4*)(lds + L_ADV + f16 * S_Z + zd);
@@ -538,7 +571,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             z4 = z4 - step * (m4 * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
                                       __builtin_amdgcn_rcpf(den.w)});
             if (zvalid) {
-                *(f4*)(zs + zd) = z4;
+                *(f4*)(zs + zd) = swz4(z4, fhi);
                 *(f4*)(lds + L_ADM + f16 * S_Z + zd) = m4;
                 *(f4*)(lds + L_ADV + f16 * S_Z + zd) = v4;
             }
@@ -557,12 +590,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     // ================= epilogue: outputs of the LAST forward pass, rebuilt from what it left in LDS
     // (y planes, qw / d, bones, tracker loss terms, the pre-step latent) -- kept out of the hot loop
     if (!optimise) { // forward-only launch: the one forward pass ran on z itself
-        if (zvalid) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = *(const f4*)(zs + zd);
+        if (zvalid) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = swz4(*(const f4*)(zs + zd), fhi);
     }
     __syncthreads();
     if (fvalid) {
         const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
-        const f4 sd = *(const f4*)icp->sd, mu = *(const f4*)icp->mu;
+        const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
         const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
         const float inv = has_quat ? __builtin_amdgcn_rsqf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z) : 0.f;
         const Q4 q = {r.w * inv, r.x * inv, r.y * inv, r.z * inv};
@@ -625,7 +658,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     }
 
     if (optimise && zvalid && blk0 + f16 < nB) {
-        if (a.z) *(f4*)(a.z + (size_t)(blk0 + f16) * LAT + zd) = *(const f4*)(zs + zd); // own write, same lane
+        if (a.z) *(f4*)(a.z + (size_t)(blk0 + f16) * LAT + zd) = swz4(*(const f4*)(zs + zd), fhi); // own write, same lane
         if (a.iters && wave == 0 && h == 0) a.iters[blk0 + f16] = a.n_iter;
     }
 }
