@@ -366,7 +366,6 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
     if (!in->z0 || !in->z_tgt || !in->cur_rot || !in->tgt_pos || !in->tgt_rot || !in->w || !in->tracked)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL input array");
     if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1,256]");
-    if (p->early_stop) return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: early_stop is not implemented in this build");
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: bad Adam hyper-parameters");
     KArgs k;
@@ -380,6 +379,8 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
     // torch passes (1-beta) as Python doubles into fp32 tensor ops
     k.beta2 = p->beta2; k.one_m_b1 = (float)(1.0 - (double)p->beta1); k.one_m_b2 = (float)(1.0 - (double)p->beta2);
     k.eps = p->eps;
+    k.early_stop = p->early_stop ? 1 : 0;
+    k.stop_eps_pos = p->stop_eps_pos; k.stop_eps_rot = p->stop_eps_rot; k.min_loss_incr = p->min_loss_incr;
     double b1t = 1.0, b2t = 1.0;
     for (int t = 0; t < p->n_iter; ++t) {
         b1t *= (double)p->beta1;

@@ -27,6 +27,8 @@ struct KArgs {
     int* iters;
     float* dbg;
     int n_frames, n_iter, mode; // mode 0: optimise, 1: forward only (n_iter = 1)
+    int early_stop;             // per-frame while-condition of drag_pose.py:300-304
+    float stop_eps_pos, stop_eps_rot, min_loss_incr;
     float lam_rot, lam_tmp, ctmp; // ctmp = 2 lam_tmp / 24
     float beta2, one_m_b1, one_m_b2, eps;
     unsigned smask[dpl::NWAVE][dpl::NGEMM]; // bit i: step i of the wave's chain has a non-zero weight block

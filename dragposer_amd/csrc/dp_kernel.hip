@@ -64,7 +64,10 @@ constexpr int L_ZT = L_BIAS + 128;                 // z_tgt [16][S_Z]
 constexpr int WB_STRIDE = 60;                      // per lane: bL2[26] pad2 | bL1[16] | bL0[10] | pad6
 constexpr int WB_B2 = 0, WB_B1 = 28, WB_B0 = 44;
 constexpr int L_ZPRE = L_ZT + FPB * S_Z;           // latent of the last forward pass [16][S_Z]
-constexpr int L_ADM = L_ZPRE + FPB * S_Z;            // Adam m [16][S_Z]   (zeroed at start: lies below L_ITEM? no -> zeroed explicitly)
+constexpr int L_ZFIN = L_ZPRE + FPB * S_Z;          // early stop: latent after a frame's last step [16][S_Z]
+constexpr int L_ES = L_ZFIN + FPB * S_Z;           // early stop: per frame {active, stop_now, iters, next_active, loss_pos, loss_rot, loss_tmp, -}
+constexpr int L_LT = L_ES + FPB * 8;               // early stop: partial sums of |z - z_tgt|^2 from the latent lanes [16][8]
+constexpr int L_ADM = L_LT + FPB * 8;            // Adam m [16][S_Z]   (zeroed at start: lies below L_ITEM? no -> zeroed explicitly)
 constexpr int L_ADV = L_ADM + FPB * S_Z;           // Adam v [16][S_Z]
 constexpr int L_WB = L_ADV + FPB * S_Z;            // wb[4 matrix waves][64 lanes][WB_STRIDE] backward weights
 constexpr int L_TOTAL = L_WB + 4 * 64 * WB_STRIDE;
@@ -186,6 +189,7 @@ DEV f4 lrelu4(f4 x) { return f4{lrelu(x.x), lrelu(x.y), lrelu(x.z), lrelu(x.w)};
 DEV f4 dlrelu4(f4 a, f4 g) { return f4{dlrelu(a.x, g.x), dlrelu(a.y, g.y), dlrelu(a.z, g.z), dlrelu(a.w, g.w)}; }
 
 // ------------------------------------------------------------------------------------------------
+template <bool EARLY>
 __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[L_TOTAL];
@@ -252,7 +256,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         *(f4*)(lds + L_ZT + f16 * S_Z + zd) = optimise ? *(const f4*)(a.z_tgt + (size_t)gf * LAT + zd) : zero4;
         *(f4*)(lds + L_ADM + f16 * S_Z + zd) = zero4;
         *(f4*)(lds + L_ADV + f16 * S_Z + zd) = zero4;
+        if (EARLY) {
+            const f4 dz = *(const f4*)(a.z0 + (size_t)gf * LAT + zd) - *(const f4*)(a.z_tgt + (size_t)gf * LAT + zd);
+            lds[L_LT + f16 * 8 + 4 * (wave & 1) + h] = dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
+        }
     }
+    if (EARLY && tid < FPB) *(f4*)(lds + L_ES + tid * 8) = f4{1.f, 0.f, 0.f, 1.f};
 
     // ---- P3 per-lane identity (a few integers stay in registers, the float constants are re-read from
     //      LDS every iteration to keep the register budget for the kinematics temporaries)
@@ -301,6 +310,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     if (it_id < MAX_ROOT_CH) *(f4*)(bone + icg->init_id * 4) = f4{icg->init_off[0], icg->init_off[1], icg->init_off[2], 0.f};
 
     f4 a0v = {0.f, 0.f, 0.f, 0.f}, a1v = a0v; // my tile of a0 / a1 (kept for the LeakyReLU derivative)
+    float es_prev = 10000000.f; // early stop, root lane: previous total loss (drag_pose.py:297), active flag, count
+    bool es_act = true;
+    int es_iters = 0;
     __syncthreads();
 #ifdef DP_PROFILE
     unsigned long long prof[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -455,6 +467,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                     for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(cqb + u * 4);
 #pragma unroll
                     for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
+                    if (EARLY) { // per-frame stop test of the reference's while loop (drag_pose.py:300-304,351-355)
+                        float lp = 0.f, lr = 0.f;
+                        for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(lpb + e0 * 2); lp += l.x; lr += l.y; }
+                        const f4 p0 = *(const f4*)(lds + L_LT + pf * 8);
+                        const f2 p1 = *(const f2*)(lds + L_LT + pf * 8 + 4);
+                        const float lt = (((p0.x + p0.y) + (p0.z + p0.w)) + (p1.x + p1.y)) * a.lam_tmp * (1.f / 24.f);
+                        const float tot = (lp + lr) + lt;
+                        const bool cont = (lp > a.stop_eps_pos || lr > a.stop_eps_rot) && (es_prev - tot > a.min_loss_incr) && !last;
+                        float* es = lds + L_ES + pf * 8;
+                        if (es_act) {
+                            es_prev = tot;
+                            ++es_iters;
+                            *(f4*)(es + 4) = f4{lp, lr, lt, 0.f}; // losses of this frame's last executed iteration
+                        }
+                        *(f4*)(es) = f4{es_act ? 1.f : 0.f, (es_act && !cont) ? 1.f : 0.f, (float)es_iters, (es_act && cont) ? 1.f : 0.f};
+                        es_act = es_act && cont;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
@@ -561,24 +590,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                 m4 = *(const f4*)(lds + L_ADM + f16 * S_Z + zd);
                 v4 = *(const f4*)(lds + L_ADV + f16 * S_Z + zd);
             }
-            if (last && zvalid) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = z4;
             const f4 g = gz + a.ctmp * (z4 - zt4);
             if (DBG_DUMP && a.dbg && iter == 0 && zvalid && blk0 + f16 < nB) *(f4*)(a.dbg + (size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + zd) = g;
+            bool f_act = true, f_stop = false;
+            if (EARLY) {
+                const f2 fl = *(const f2*)(lds + L_ES + f16 * 8);
+                f_act = fl.x != 0.f;
+                f_stop = fl.y != 0.f;
+            }
+            if (zvalid && f_act && (EARLY || last)) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = z4; // latent of this forward pass
             m4 = m4 + a.one_m_b1 * (g - m4);
             v4 = v4 * a.beta2 + a.one_m_b2 * (g * g);
             const f4 den = f4{__builtin_amdgcn_sqrtf(v4.x), __builtin_amdgcn_sqrtf(v4.y), __builtin_amdgcn_sqrtf(v4.z),
                               __builtin_amdgcn_sqrtf(v4.w)} * rbc2s + a.eps;
             z4 = z4 - step * (m4 * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
                                       __builtin_amdgcn_rcpf(den.w)});
-            if (zvalid) {
-                *(f4*)(zs + zd) = swz4(z4, fhi);
-                *(f4*)(lds + L_ADM + f16 * S_Z + zd) = m4;
-                *(f4*)(lds + L_ADV + f16 * S_Z + zd) = v4;
+            if (zvalid && f_act) {
+                if (EARLY && f_stop) {
+                    // this frame's loop ends here: keep the stepped latent aside and leave zs at the pre-step latent, so
+                    // that the (wasted) forward passes of the remaining iterations reproduce this one bit for bit
+                    *(f4*)(lds + L_ZFIN + f16 * S_Z + zd) = z4;
+                } else {
+                    *(f4*)(zs + zd) = swz4(z4, fhi);
+                    *(f4*)(lds + L_ADM + f16 * S_Z + zd) = m4;
+                    *(f4*)(lds + L_ADV + f16 * S_Z + zd) = v4;
+                    if (EARLY) {
+                        const f4 dz = z4 - zt4;
+                        lds[L_LT + f16 * 8 + 4 * (wave & 1) + h] = dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
+                    }
+                }
             }
         }
         STAMP(14);
         __syncthreads();
         STAMP(15);
+        if (EARLY) { // every frame of the workgroup has stopped (same LDS words for all waves: uniform)
+            if (__ballot(lds[L_ES + (lane & 15) * 8 + 3] != 0.f) == 0ull) break;
+        }
     }
 #ifdef DP_PROFILE
     if (a.dbg && tid == 0) {
@@ -630,7 +678,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         }
         if (is_root) {
             if (a.world_rot) { float* o = a.world_rot + (size_t)gfp * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
-            if (optimise) {
+            if (optimise && EARLY) {
+                const float* es = lds + L_ES + pf * 8;
+                const float* zrow = lds + L_ZPRE + pf * S_Z;
+                for (int k = 0; k < LAT; k += 4)
+                    if (a.z_pre) *(f4*)(a.z_pre + (size_t)gfp * LAT + k) = *(const f4*)(zrow + k);
+                if (a.loss) { a.loss[(size_t)gfp * 3 + 0] = es[4]; a.loss[(size_t)gfp * 3 + 1] = es[5]; a.loss[(size_t)gfp * 3 + 2] = es[6]; }
+                if (a.iters) a.iters[gfp] = (int)es[2];
+            } else if (optimise) {
                 float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
                 for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(lpb + e0 * 2); lsum_p += l.x; lsum_r += l.y; }
                 const float* zrow = lds + L_ZPRE + pf * S_Z;
@@ -657,16 +712,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         }
     }
 
-    if (optimise && zvalid && blk0 + f16 < nB) {
-        if (a.z) *(f4*)(a.z + (size_t)(blk0 + f16) * LAT + zd) = swz4(*(const f4*)(zs + zd), fhi); // own write, same lane
-        if (a.iters && wave == 0 && h == 0) a.iters[blk0 + f16] = a.n_iter;
+    if (optimise && zvalid && blk0 + f16 < nB) { // own writes, same lane
+        if (a.z) *(f4*)(a.z + (size_t)(blk0 + f16) * LAT + zd) = EARLY ? *(const f4*)(lds + L_ZFIN + f16 * S_Z + zd) : swz4(*(const f4*)(zs + zd), fhi);
+        if (!EARLY && a.iters && wave == 0 && h == 0) a.iters[blk0 + f16] = a.n_iter;
     }
 }
 
 extern "C" hipError_t dp_launch_optimize(const KArgs* args, hipStream_t stream)
 {
     const int grid = (args->n_frames + FPB - 1) / FPB;
-    hipLaunchKernelGGL(dp_optimize_kernel, dim3(grid), dim3(NTHREADS), 0, stream, *args);
+    if (args->early_stop)
+        hipLaunchKernelGGL(dp_optimize_kernel<true>, dim3(grid), dim3(NTHREADS), 0, stream, *args);
+    else
+        hipLaunchKernelGGL(dp_optimize_kernel<false>, dim3(grid), dim3(NTHREADS), 0, stream, *args);
     return hipGetLastError();
 }
 

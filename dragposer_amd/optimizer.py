@@ -85,10 +85,13 @@ class LatentOptimizer:
         return res, tensors
 
     def optimize(self, z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter=50, lr=1e-2, betas=(0.9, 0.999),
-                 eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, outputs=None, out=None, _debug=None):
+                 eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=None,
+                 outputs=None, out=None, _debug=None):
         """All inputs are device tensors: z0/z_tgt [B,24], cur_rot [B,4], tgt_pos [B,22,3],
         tgt_rot [B,22,9], w [B,22,2] (fp32) and tracked [B,22] (uint8).  Returns a dict of device
-        tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream."""
+        tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream.
+        With stop_eps_* > 0 or min_loss_incr given, every frame runs the reference's own while-condition
+        (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter)."""
         B = int(z0.shape[0])
         dev = self.device
         batch = _lib.DpBatch()
@@ -100,8 +103,10 @@ class LatentOptimizer:
         batch.tgt_rot = _check(tgt_rot, "tgt_rot", (B, NJ, 9), torch.float32, dev)
         batch.w = _check(w, "w", (B, NJ, 2), torch.float32, dev)
         batch.tracked = _check(tracked, "tracked", (B, NJ), torch.uint8, dev)
+        early = min_loss_incr is not None or stop_eps_pos > 0 or stop_eps_rot > 0
         p = _lib.DpParams(n_iter=int(n_iter), lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, lambda_rot=lambda_rot,
-                          lambda_tmp=lambda_tmp, early_stop=0, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=0.0)
+                          lambda_tmp=lambda_tmp, early_stop=int(early), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
+                          min_loss_incr=float("-inf") if min_loss_incr is None else min_loss_incr)
         names = tuple(outputs) if outputs is not None else tuple(_OUT_SPECS)
         res, tensors = self._outputs(B, names, out)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -143,6 +143,24 @@ def test_golden_parity_3_trackers_100_iters(opt, golden_dir):
     np.testing.assert_allclose(tot[sens], tot_ref[sens], rtol=0.1)  # same optimum quality where the path diverged
 
 
+def test_early_stop_matches_reference_loop(opt, golden_dir):
+    """The reference's own eval settings (eval_drag.py:210-214): stop_eps_pos 1e-4, stop_eps_rot 1e-2,
+    max_iter 100, min_loss_incr 1e-5 -- iteration counts, returned pose and stepped latent per frame."""
+    g = R.load_golden(os.path.join(golden_dir, "es.npz"))
+    mt = g["meta"]
+    o = _run(opt, g, mt["n_iter"], mt["lambda_tmp"], stop_eps_pos=mt["stop_eps_pos"], stop_eps_rot=mt["stop_eps_rot"],
+             min_loss_incr=mt["min_loss_incr"])
+    assert g["iters"].min() < 20 and g["iters"].max() == 100  # the fixture exercises both exits
+    same = o["iters"] == g["iters"]
+    # the loss increment sits within rounding of the 1e-5 threshold on a few frames: allow +-1 iteration on <= 5 %
+    assert same.mean() >= 0.95 and np.abs(o["iters"] - g["iters"]).max() <= 1, (same.mean(), np.abs(o["iters"] - g["iters"]).max())
+    assert _mm(o["pos"][same], g["pos"][same]).max() <= 0.05
+    np.testing.assert_allclose(o["z"][same], g["z_final"][same], atol=5e-5)
+    np.testing.assert_allclose(o["z_pre"][same], g["z_pre"][same], atol=5e-5)
+    last = g["loss_hist"][np.arange(len(g["iters"])), g["iters"] - 1]
+    np.testing.assert_allclose(o["loss"][same], last[same], rtol=2e-3, atol=1e-8)
+
+
 @pytest.mark.parametrize("B", [1, 15, 17, 33])
 def test_ragged_batches_equal_full_batch_rows(opt, golden_dir, B):
     g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
