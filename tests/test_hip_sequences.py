@@ -1,0 +1,72 @@
+"""GPU: the full per-frame operator -- warm-started latent, temporal target block, early-stopped optimise
+loop in the HIP kernel, epilogue with joint adjustment and ring buffers -- driven
+frame by frame with the targets the REAL reference saw (tests/golden/seq*.npz, produced by running the
+reference's DragPose.run over whole sequences with its own Temporal class)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from test_temporal import _load_temporal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["seq6", "seq3"])
+def test_sequences_track_the_reference_state_machine(golden_dir, name):
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    g = R.load_golden(os.path.join(golden_dir, f"{name}.npz"))
+    mt, cfg = g["meta"], g["meta"]["cfg"]
+    K, T = mt["K"], mt["T"]
+    opt = LatentOptimizer(device="cuda:0")
+    dp = DragPose(opt, _load_temporal(g), g["means_latent"], g["stds_latent"], n_sequences=K)
+    dp.set_initial_state(g["z0"], np.zeros((K, 3), np.float32), g["init_rot"], g["init_heights"])
+    ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
+    iters_equal, gpos_mm, rot_err, pose_err = [], [], [], []
+    for t in range(T):
+        pose, gpos = dp.run(g["tgt_pos"][t], g["tgt_rot"][t], g["mask_idx"], g["weights"], offsets=opt.host_model.arrays["offsets"],
+                            stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-2,
+                            lambda_rot=1, lambda_temporal=cfg["lambda_temporal"], temporal_future_window=cfg["temporal_future_window"],
+                            joint_adjustment_indices=ja, joint_adjustment_weight=cfg["joint_adjustment_weight"])  # eval_drag.py:204-222
+        iters_equal.append(dp.last["iters"].cpu().numpy() == g["iters"][t])
+        gpos_mm.append(np.abs(gpos.cpu().numpy() - g["gpos_ret"][t]).max() * 1000.0)
+        rot_err.append(np.abs(dp.current_global_rot.cpu().numpy() - g["cur_rot"][t]).max())
+        pose_err.append(np.abs(pose.cpu().numpy() - g["pose_ret"][t]).max())
+    iters_equal, gpos_mm = np.array(iters_equal), np.array(gpos_mm)
+    # the same number of optimiser iterations on (almost) every frame of every sequence, with both loop exits exercised
+    assert iters_equal.mean() >= 0.97, iters_equal.mean()
+    assert g["iters"].max() >= 50 and g["iters"].min() <= 3
+    # accumulated root trajectory: 0.05 mm over the first 20 frames; state feedback may amplify a rounding-level Adam
+    # sign flip afterwards (seen on the last frame of both fixtures), bounded at 1 mm
+    assert gpos_mm[:20].max() <= 0.05 and gpos_mm.max() <= 1.0, (gpos_mm[:20].max(), gpos_mm.max())
+    assert max(rot_err[:20]) <= 2e-5 and max(pose_err[:20]) <= 5e-3
+    # ring buffers after the last frame (row a13)
+    for k in range(K):
+        np.testing.assert_allclose(dp.displacement_buffer[k].cpu().numpy()[:-4], g[f"final_displacement_buffer_{k}"][:-4], atol=1e-5)
+        np.testing.assert_allclose(dp.heights_buffer[k].cpu().numpy()[:-4], g[f"final_heights_buffer_{k}"][:-4], atol=2e-5)
+        np.testing.assert_allclose(dp.latent_buffer[k].cpu().numpy()[:-4], g[f"final_latent_buffer_{k}"][:-4], atol=2e-3)
+
+
+def test_single_sequence_keeps_reference_shapes():
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+    from dragposer_amd.temporal import TemporalPredictor
+
+    torch.manual_seed(0)
+    opt = LatentOptimizer(device="cuda:0")
+    dp = DragPose(opt, TemporalPredictor(n_encoder_layers=1, n_decoder_layers=1, dim_feedforward=16), np.zeros(24), np.ones(24))
+    m = R.OracleModel()
+    b = R.synth_inputs(m, 1)
+    dp.set_initial_state(b["z0"], np.zeros(3), b["cur_rot"], np.zeros(6))
+    idx = np.array(R.TRACK6)
+    pose, gpos = dp.run(torch.tensor(b["tgt_pos"][0, idx]), torch.tensor(b["tgt_rot"][0, idx]).reshape(6, 3, 3), idx,
+                        np.array([R.W6[j] for j in R.TRACK6], np.float32), max_iter=10, learning_rate=1e-2, lambda_temporal=0.02,
+                        temporal_future_window=0)
+    assert tuple(pose.shape) == (88,) and tuple(gpos.shape) == (3,)  # drag_pose.py:414
+    assert torch.isfinite(pose).all()
+    with pytest.raises(ValueError):
+        dp.run(torch.zeros(5, 3), torch.zeros(6, 3, 3), idx, np.ones((6, 2), np.float32))

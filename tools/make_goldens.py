@@ -307,9 +307,98 @@ def anchors(parents, offsets_t):
     print("A1 motion[:8]", a1["motion"][:8], "\nA2 losses", a2["losses"], "\nA2 grad[:4]", a2["grad"][:4])
 
 
+TEMPORAL_SMALL = dict(n_encoder_layers=1, n_decoder_layers=1, dim_feedforward=32)  # keeps the fixture small
+
+
+def run_sequences(name, K, T, cfg, offsets_t, parents, seed):
+    """K sequences x T frames through the REAL DragPose.run with all its state (warm-started latent, global
+    position / rotation, ring buffers, temporal target block, joint adjustment, early stop) -- SURVEY rows a11-a13.
+    The temporal predictor is the reference's Temporal class with seeded random weights (temporal.pt is
+    missing from the mount) and a reduced width so that its state_dict fits a fixture."""
+    import copy
+
+    import train_temporal as ref_tt
+    from temporal_transformer import Temporal
+
+    torch.manual_seed(seed)
+    tparam = copy.deepcopy(ref_tt.param)
+    tparam.update(TEMPORAL_SMALL)
+    temporal = Temporal(tparam, "cpu")
+    temporal.eval()
+    means_latent = 0.1 * torch.randn(24)
+    stds_latent = 0.5 + torch.rand(24)
+    td = Train_Data("cpu", ref_train.param, None)
+    gm = Generator_Model("cpu", ref_train.param, list(int(p) for p in parents), td)
+    ref_train.load_model(gm, os.path.join(REF, "models/model_dancedb/generator.pt"), td, "cpu")
+    drag = RecordingDragPose(gm, temporal, means_latent, stds_latent, "cpu", "cpu")
+    mask = torch.tensor(cfg["mask"])
+    idx = torch.nonzero(mask).squeeze()
+    wj = torch.tensor(cfg["weights"], dtype=torch.float32)[idx]
+    E = int(idx.numel())
+    height_idx = [0, 4, 8, 13, 17, 21]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = dict(
+        z0=np.zeros((K, 24), np.float32), init_rot=np.zeros((K, 4), np.float32), init_heights=np.zeros((K, 6), np.float32),
+        tgt_pos=np.zeros((T, K, E, 3), np.float32), tgt_rot=np.zeros((T, K, E, 3, 3), np.float32),
+        pose_ret=np.zeros((T, K, 88), np.float32), gpos_ret=np.zeros((T, K, 3), np.float32), iters=np.zeros((T, K), np.int32),
+        latent=np.zeros((T, K, 24), np.float32), cur_rot=np.zeros((T, K, 4), np.float32), z_tgt=np.zeros((T, K, 24), np.float32),
+        mask_idx=idx.numpy().astype(np.int32), weights=wj.numpy(), means_latent=means_latent.numpy(), stds_latent=stds_latent.numpy(),
+    )
+    for k in range(K):
+        zgt = torch.randn(24, generator=g) * 0.3
+        cr = torch.randn(4, generator=g)
+        cr = cr / torch.linalg.norm(cr)
+        z0 = zgt + 0.05 * torch.randn(24, generator=g)
+        pos0, _, _, _ = forward_fk(drag, td, z0, cr, offsets_t)
+        reset_state(drag, z0, cr)
+        heights0 = pos0[height_idx, 1].clone()
+        drag.heights_buffer[:] = heights0
+        out["z0"][k], out["init_rot"][k], out["init_heights"][k] = z0.numpy(), cr.numpy(), heights0.numpy()
+        gt_rot, gt_pos = cr.clone(), torch.zeros(3)
+        for t in range(T):
+            zgt = zgt + 0.02 * torch.randn(24, generator=g)
+            with torch.no_grad():
+                motion, disp = drag.decoder(zgt.reshape(1, 24), td.mean_dqs, td.std_dqs)
+                qs = (motion * drag.stds_dqs + drag.means_dqs)[0, :, 0].reshape(NJ, 4)
+                d = (disp * drag.stds_displacement + drag.means_displacement)[0, :, 0]
+                gt_rot = ref_drag_pose.quat.mul(gt_rot.reshape(1, 4), qs[0:1]).reshape(4)
+                gt_pos = gt_pos + ref_drag_pose.quat.mul_vec(gt_rot.reshape(1, 4), d.reshape(1, 3)).reshape(3)
+                qs_t = qs.clone()
+                qs_t[0] = gt_rot
+                rotm = ref_utils.from_root_quat_to_rotmat(qs_t.reshape(1, 1, NJ, 4), torch.tensor(drag.parents))
+                rel = (gt_pos - drag.current_global_pos.detach()[0, :, 0]).reshape(1, 1, 3)  # eval_drag.py:186
+                pos_t, rot_t = ref_utils.fk_rotmat(rotm, rel, offsets_t, drag.parents)
+            tp, tR = pos_t[0, 0, idx].clone(), rot_t[0, 0, idx].clone()
+            n0 = len(drag.rec)
+            ci = drag.current_index
+            ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
+            pose_ret, gpos_ret = drag.run(
+                target_ee_pos=tp, target_ee_rot=tR, mask_joints=idx, weights_joints=wj, offsets=offsets_t,
+                stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-2,
+                lambda_rot=1, lambda_temporal=cfg["lambda_temporal"], temporal_future_window=cfg["temporal_future_window"],
+                height_indices=height_idx, joint_adjustment_indices=ja, joint_adjustment_weight=cfg["joint_adjustment_weight"],
+                verbose=False)
+            out["tgt_pos"][t, k], out["tgt_rot"][t, k] = tp.numpy(), tR.numpy()
+            out["pose_ret"][t, k] = pose_ret.detach().reshape(88).numpy()
+            out["gpos_ret"][t, k] = gpos_ret.detach().reshape(3).numpy()
+            out["iters"][t, k] = len(drag.rec) - n0
+            out["latent"][t, k] = drag.latent.detach().reshape(24).numpy()
+            out["cur_rot"][t, k] = drag.current_global_rot.detach().reshape(4).numpy()
+            out["z_tgt"][t, k] = drag.target_latent_buffer[ci].detach().reshape(24).numpy()
+        print(f"[{name}] sequence {k}: iters {out['iters'][:, k].tolist()}", flush=True)
+        out[f"final_latent_buffer_{k}"] = drag.latent_buffer.detach().numpy().copy()
+        out[f"final_displacement_buffer_{k}"] = drag.displacement_buffer.detach().numpy().copy()
+        out[f"final_heights_buffer_{k}"] = drag.heights_buffer.detach().numpy().copy()
+    for key, v in temporal.state_dict().items():
+        out["temporal." + key] = v.numpy()
+    meta = dict(name=name, K=K, T=T, cfg=cfg, temporal_param=TEMPORAL_SMALL, seed=seed, torch=torch.__version__)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es")
+    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3")
     ap.add_argument("--frames", type=int, default=64)
     args = ap.parse_args()
     todo = args.only.split(",")
@@ -338,6 +427,12 @@ def main():
     for name, kw in jobs.items():
         if name in todo:
             out = run_recipe(name, B, offsets_t=offsets_t, parents=parents, **kw)
+            path = os.path.join(gold, f"{name}.npz")
+            np.savez_compressed(path, **out)
+            print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78)):
+        if name in todo:
+            out = run_sequences(name, K, T, cfg, offsets_t, parents, seed)
             path = os.path.join(gold, f"{name}.npz")
             np.savez_compressed(path, **out)
             print("wrote", path, os.path.getsize(path), "bytes", flush=True)
