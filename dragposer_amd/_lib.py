@@ -83,6 +83,14 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  dragposer_amd has no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the device pointers / streams
+    # it hands us are only meaningful to THAT runtime.  Import torch (and pin its copy) before our library is
+    # resolved, so that the shared SONAME binds libdragposer_hip.so to torch's runtime, never to /opt/rocm's.
+    import torch
+
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     lib.dp_version.restype = C.c_int
     lib.dp_last_error.restype = C.c_char_p
