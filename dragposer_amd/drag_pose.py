@@ -58,7 +58,7 @@ class DragPose:
         assert window % SAMPLE_STEP == 0
         if self.target_latent_buffer is None or self.target_latent_buffer.shape[1] != window + 1:
             self.target_latent_buffer = torch.zeros(S, window + 1, LATENT, device=dev)
-        if self.current_index != 0:
+        if self.current_index != 0 or self.temporal is None:  # no predictor: the buffer stays zero, use lambda_temporal = 0
             return
         idx = self.temporal_frames_index
         with torch.no_grad():

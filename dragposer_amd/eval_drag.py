@@ -1,0 +1,160 @@
+"""`eval_drag` on MI355X: the reference's offline evaluation CLI (python/src/eval_drag.py:21-293) with the
+per-frame optimisation running in the HIP kernel.
+
+    python -m dragposer_amd.eval_drag [model.npz] input.bvh --config config/6_trackers_config.json
+
+Same positional arguments / --config / --verbose and the same JSON keys as the reference.  Differences,
+all stated in the output: the model is the flat fixture (tensors of generator.pt + data.pt), and because the
+reference's temporal.pt is not distributed with it the temporal predictor is optional: without
+--temporal-checkpoint the pull term is switched off (lambda_temporal = 0) instead of pulling towards the
+predictions of an untrained network.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import quat_np as Q
+from .bvh import BVH
+from .drag_pose import DragPose
+from .encoder import PoseEncoder
+from .model import DEFAULT_MODEL, NJ
+from .motion import local_quats_from_bvh, prepare_motion
+from .optimizer import LatentOptimizer
+from .temporal import load_reference_checkpoint
+
+SPARSE_JOINTS = [0, 4, 8, 13, 17, 21]  # train.py:32-39 (evaluation only)
+HEIGHT_INDICES = [0, 4, 8, 13, 17, 21]
+
+DEFAULT_CONFIG = dict(  # eval_drag.py:68-131
+    mask=[1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1],
+    weights=[[10, 10]] + [[1, 0.01]] * 2 + [[5, 0.01]] + [[1, 0.01]] * 3 + [[5, 0.01]] + [[1, 0.01]] * 5 + [[5, 0.01]]
+    + [[1, 0.01]] * 3 + [[5, 0.01]] + [[1, 0.01]] * 3 + [[5, 0.01]],
+    enable_joint_adjustment=True, joint_adjustment_indices=[0, 0], joint_adjustment_weight=1.0,
+    lambda_temporal=0.02, temporal_future_window=0)
+
+
+def eval_pos_error(gt_bvh, eval_bvh):
+    """eval_metrics.eval_pos_error (eval_metrics.py:6-32): FK of both files with the root at the origin."""
+    gq, _, parents, offsets = local_quats_from_bvh(gt_bvh)
+    eq, _, _, _ = local_quats_from_bvh(eval_bvh)
+    n = min(len(gq), len(eq))
+    gp, _ = Q.fk(gq[:n], np.zeros((n, 3)), offsets, parents)
+    ep, _ = Q.fk(eq[:n], np.zeros((n, 3)), offsets, parents)
+    err = np.linalg.norm(ep - gp, axis=-1)
+    return float(err.mean()), float(err[:, SPARSE_JOINTS[1:]].mean())
+
+
+def result_to_bvh(poses, global_pos, means, stds, bvh, out_path):
+    """train.result_to_bvh with are_root_rot_incr=False (train.py:437-509): normalised root-space quaternions
+    whose root channels already hold the world rotation -> local Euler angles -> BVH."""
+    sd4 = stds["dqs"].reshape(NJ, 8)[:, :4].reshape(88)
+    mu4 = means["dqs"].reshape(NJ, 8)[:, :4].reshape(88)
+    qs = (poses.astype(np.float64) * sd4 + mu4).reshape(-1, NJ, 4)
+    _, _, parents, _, order = bvh.get_data()
+    local = Q.from_root_space(qs, parents)
+    rot = np.stack([np.degrees(Q.to_euler(local[:, j], order[j])) for j in range(NJ)], axis=1)
+    bvh.set_data(rot, global_pos.astype(np.float64))
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    bvh.save(out_path)
+
+
+def evaluate_file(args, input_path, opt, encoder, temporal_pack, cfg, raw):
+    dev = opt.device
+    means = {"dqs": raw["means.dqs"], "displacement": raw["means.displacement"]}
+    stds = {"dqs": raw["stds.dqs"], "displacement": raw["stds.displacement"]}
+    bvh = BVH().load(input_path)
+    m = prepare_motion(bvh, means, stds, HEIGHT_INDICES)
+    if not np.allclose(m["offsets"], opt.host_model.arrays["offsets"], atol=1e-5) or list(m["parents"]) != list(opt.host_model.parents):
+        raise SystemExit(f"{input_path}: skeleton differs from the one the model fixture was exported with")
+    n_frames = len(m["dqs"]) if args.max_frames is None else min(args.max_frames, len(m["dqs"]))
+    mask_idx = np.nonzero(np.asarray(cfg["mask"]))[0]
+    weights = np.asarray(cfg["weights"], np.float32)[mask_idx]
+    temporal, means_latent, stds_latent = temporal_pack
+    lam_tmp = cfg["lambda_temporal"] if temporal is not None else 0.0
+    window = cfg["temporal_future_window"] if temporal is not None else 0
+
+    # targets (eval_drag.py:164-202): FK of the ground-truth pose with the root at the origin, per frame; the
+    # root translation relative to the running estimate is added inside the loop, on the device
+    rq = m["root_quats"].copy()
+    rq[:, 0] = m["global_rot"]
+    local = Q.from_root_space(rq, m["parents"])
+    p_rel, g_rot = Q.fk(local[:n_frames], np.zeros((n_frames, 3)), m["offsets"].astype(np.float64), m["parents"])
+    tp_rel = torch.tensor(p_rel[:, mask_idx], dtype=torch.float32, device=dev)
+    tR = torch.tensor(Q.to_matrix(g_rot[:, mask_idx]).reshape(n_frames, len(mask_idx), 9), dtype=torch.float32, device=dev)
+    gpos = torch.tensor(m["global_pos"], device=dev)
+
+    drag = DragPose(opt, temporal, means_latent, stds_latent, n_sequences=1)
+    gen = torch.Generator(device="cpu").manual_seed(2222)  # train.param["seed"]
+    z0 = encoder.sample(torch.tensor(m["dqs"][0:1], device=dev), generator=gen)  # drag_pose.py:50
+    drag.set_initial_state(z0, m["global_pos"][0], m["global_rot"][0], m["heights"][0])
+    ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
+    poses = torch.zeros(n_frames, 88, device=dev)
+    out_pos = torch.zeros(n_frames, 3, device=dev)
+    iters = torch.zeros(n_frames, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(n_frames):
+        if i % 1000 == 0:
+            print(f"Frame: {i + 1} out of {n_frames}", flush=True)
+        tp = tp_rel[i:i + 1] + (gpos[i] - drag.current_global_pos).unsqueeze(1)  # eval_drag.py:186-199
+        pose, pos = drag.run(tp, tR[i:i + 1], mask_idx, weights, stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=args.max_iter,
+                             min_loss_incr=0.00001, learning_rate=1e-2, lambda_rot=1, lambda_temporal=lam_tmp,
+                             temporal_future_window=window, height_indices=HEIGHT_INDICES, joint_adjustment_indices=ja,
+                             joint_adjustment_weight=cfg["joint_adjustment_weight"], verbose=args.verbose)
+        poses[i], out_pos[i], iters[i] = pose[0], pos[0], drag.last["iters"][0]
+    torch.cuda.synchronize()
+    elapsed = time.time() - t0
+    name = os.path.basename(input_path)
+    out_path = os.path.join(args.out_dir, "eval_" + name)
+    result_to_bvh(poses.cpu().numpy(), out_pos.cpu().numpy(), means, stds, bvh, out_path)
+    mpjpe, mpeepe = eval_pos_error(BVH().load(input_path), BVH().load(out_path))
+    print(f"Evaluate Loss: {mpjpe + mpeepe}")
+    print(f"Mean Per Joint Position Error: {mpjpe}")
+    print(f"Mean End Effector Position Error: {mpeepe}")
+    print(f"Time: {elapsed}")
+    print(f"Frames: {n_frames}  ({n_frames / elapsed:.1f} frames/s, mean iterations/frame {iters.float().mean().item():.1f}, "
+          f"lambda_temporal {lam_tmp}{'' if temporal is not None else ' -- no temporal checkpoint given: pull term off'})")
+    return dict(mpjpe=mpjpe, mpeepe=mpeepe, time=elapsed, frames=n_frames, out=out_path, mean_iters=iters.float().mean().item())
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Evaluate DragPoser (HIP backend)")
+    ap.add_argument("model_path", nargs="?", default=DEFAULT_MODEL, help="model fixture (.npz); default: the shipped model_dancedb")
+    ap.add_argument("input_path", help=".bvh file or a directory of .bvh files")
+    ap.add_argument("--config", default=None, help="tracker config JSON (same keys as the reference's config/*.json)")
+    ap.add_argument("--temporal-checkpoint", default=None, help="temporal.pt as saved by the reference's train_temporal.py")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--max-iter", type=int, default=100)
+    ap.add_argument("--max-frames", type=int, default=None)
+    ap.add_argument("--out-dir", default="data")
+    ap.add_argument("--device", default="cuda:0")
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("eval_drag needs a ROCm GPU: dragposer_amd has no CPU fallback")
+    cfg = dict(DEFAULT_CONFIG)
+    if args.config is not None:
+        with open(args.config) as f:
+            cfg = json.load(f)
+    raw = np.load(args.model_path)
+    opt = LatentOptimizer(args.model_path, device=args.device)
+    encoder = PoseEncoder(args.model_path).to(opt.device)
+    if args.temporal_checkpoint is not None:
+        temporal_pack = load_reference_checkpoint(args.temporal_checkpoint, opt.device)
+    else:
+        temporal_pack = (None, np.zeros(24, np.float32), np.ones(24, np.float32))
+    files = [args.input_path]
+    if os.path.isdir(args.input_path):
+        files = sorted(os.path.join(args.input_path, f) for f in os.listdir(args.input_path) if f.endswith(".bvh"))
+    results = []
+    for f in files:
+        print(f"Evaluate {f} ------------------------")
+        results.append(evaluate_file(args, f, opt, encoder, temporal_pack, cfg, raw))
+    return results
+
+
+if __name__ == "__main__":
+    main()

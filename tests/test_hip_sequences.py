@@ -70,3 +70,19 @@ def test_single_sequence_keeps_reference_shapes():
     assert torch.isfinite(pose).all()
     with pytest.raises(ValueError):
         dp.run(torch.zeros(5, 3), torch.zeros(6, 3, 3), idx, np.ones((6, 2), np.float32))
+
+
+def test_eval_drag_cli_on_bvh_clip(tmp_path):
+    """BASELINE config 1 plumbing (eval_drag on a BVH, 6 trackers): the tracked end effectors are
+    reconstructed to centimetre level and the result file round-trips (the full example.bvh numbers are in DESIGN.md)."""
+    import os
+
+    from dragposer_amd import eval_drag
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = eval_drag.main([os.path.join(root, "tests", "data", "example_clip.bvh"),
+                          "--config", os.path.join(root, "dragposer_amd", "config", "6_trackers_config.json"),
+                          "--out-dir", str(tmp_path)])[0]
+    assert res["frames"] == 240 and os.path.exists(res["out"])
+    assert res["mpeepe"] < 0.05 and res["mpjpe"] < 0.08, res  # metres; the paper-level accuracy is a few cm
+    assert res["mean_iters"] < 60
