@@ -185,6 +185,18 @@ template <int N> DEV f4 mfma_chain(const float (&w)[N], const float (&b)[N], uns
 // K-group h^2.  (Involution; P3 / epilogue readers of a quad apply swz4 again.)
 DEV f4 swz4(f4 v, bool hi) { return hi ? f4{v.z, v.w, v.x, v.y} : v; }
 
+// same without masks, for the dense products (no branches between the MFMAs)
+template <int N> DEV f4 mfma_chain_dense(const float (&w)[N], const float (&b)[N], f4 acc0)
+{
+    f4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i & 1) acc1 = mfma4(w[i], b[i], acc1);
+        else acc0 = mfma4(w[i], b[i], acc0);
+    }
+    return acc0 + acc1;
+}
+
 DEV f4 lrelu4(f4 x) { return f4{lrelu(x.x), lrelu(x.y), lrelu(x.z), lrelu(x.w)}; }
 DEV f4 dlrelu4(f4 a, f4 g) { return f4{dlrelu(a.x, g.x), dlrelu(a.y, g.y), dlrelu(a.z, g.z), dlrelu(a.w, g.w)}; }
 
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
+        const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter]; // scalar loads, issued a whole iteration ahead of their use
 
         // ================= L0: a0 = lrelu(A0 z + c0)   (24 -> 40), tiles on waves 0..2
         if (wave < 3) {
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             float w[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) w[i] = W[W_OFF_L0 + i];
-            a0v = lrelu4(mfma_chain<6>(w, b, 0x3Fu, bias));
+            a0v = lrelu4(mfma_chain_dense<6>(w, b, bias));
             *(f4*)(a0r + 16 * wave + 4 * h) = swz4(a0v, fhi);
         }
         STAMP(0);
@@ -581,8 +594,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         if (wave < 2) {
             float b[10];
             load_b<10>(a0r, hs, 0, b);
-            const f4 gz = mfma_chain<10>(WB0, b, 0x3FFu, f4{0.f, 0.f, 0.f, 0.f});
-            const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
+            // Adam state of my 4 latent dims: independent of the product, fetched while it runs
             f4 z4 = {0.f, 0.f, 0.f, 0.f}, zt4 = z4, m4 = z4, v4 = z4;
             if (zvalid) {
                 z4 = swz4(*(const f4*)(zs + zd), fhi);
@@ -590,14 +602,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
                 m4 = *(const f4*)(lds + L_ADM + f16 * S_Z + zd);
                 v4 = *(const f4*)(lds + L_ADV + f16 * S_Z + zd);
             }
-            const f4 g = gz + a.ctmp * (z4 - zt4);
-            if (DBG_DUMP && a.dbg && iter == 0 && zvalid && blk0 + f16 < nB) *(f4*)(a.dbg + (size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + zd) = g;
             bool f_act = true, f_stop = false;
             if (EARLY) {
                 const f2 fl = *(const f2*)(lds + L_ES + f16 * 8);
                 f_act = fl.x != 0.f;
                 f_stop = fl.y != 0.f;
             }
+            const f4 gz = mfma_chain_dense<10>(WB0, b, f4{0.f, 0.f, 0.f, 0.f});
+            const f4 g = gz + a.ctmp * (z4 - zt4);
+            if (DBG_DUMP && a.dbg && iter == 0 && zvalid && blk0 + f16 < nB) *(f4*)(a.dbg + (size_t)(blk0 + f16) * DBG_STRIDE + DBG_GZ + zd) = g;
             if (zvalid && f_act && (EARLY || last)) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = z4; // latent of this forward pass
             m4 = m4 + a.one_m_b1 * (g - m4);
             v4 = v4 * a.beta2 + a.one_m_b2 * (g * g);

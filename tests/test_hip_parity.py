@@ -200,6 +200,35 @@ def test_full_size_batch_properties(opt, dev):
     assert np.isfinite(o1["z"]).all()
 
 
+@pytest.mark.parametrize("n_trk", [9, 22])
+def test_more_than_six_trackers_general_path(opt, dev, n_trk):
+    """Any joint may carry a tracker (the kernel's first 6 ranks are the fast path): 9 and all 22 joints, with
+    per-joint weights, against the C oracle."""
+    from dragposer_amd.optimizer import to_device_batch
+
+    m = R.OracleModel()
+    b = R.synth_inputs(m, 48)
+    rs = np.random.RandomState(3)
+    with torch.no_grad():
+        mo, d = R.decoder_forward(m, torch.tensor(b["z_src"]))
+        _, _, pos, rot, _ = R.pose_fk(m, mo, d, torch.tensor(b["cur_rot"]))
+    b["tracked"][:] = 0
+    b["w"][:] = 0
+    for f in range(48):
+        js = np.sort(rs.permutation(22)[:n_trk])
+        b["tracked"][f, js] = 1
+        b["w"][f, js, 0] = rs.uniform(1, 10, n_trk)
+        b["w"][f, js, 1] = rs.uniform(0.01, 2, n_trk)
+    trk = b["tracked"].astype(bool)[..., None]
+    b["tgt_pos"] = (pos.numpy() * trk).astype(np.float32)
+    b["tgt_rot"] = (rot.numpy().reshape(48, 22, 9) * trk).astype(np.float32)
+    o = {k: v.cpu().numpy() for k, v in opt.optimize(**to_device_batch(b, dev), n_iter=30).items()}
+    sens, ref = _sensitive_frames(b, 30, 0.02)
+    err = _mm(o["pos"], ref["pos"]).max(axis=1)
+    assert sens.sum() <= 2 and err[~sens].max() <= 0.05, (sens.sum(), err[~sens].max())
+    np.testing.assert_allclose(o["loss"][~sens], ref["loss"][~sens], rtol=2e-3, atol=1e-8)
+
+
 def test_argument_validation(opt, dev, golden_dir):
     from dragposer_amd import _lib
     from dragposer_amd.optimizer import to_device_batch
