@@ -37,6 +37,14 @@ class DragPose:
         self.target_latent_buffer = None
         self.latent = None
         self.last = None
+        self._idx_cache = {}
+
+    def _index(self, values):
+        """device index tensor for a Python list, created once (no host->device copy inside a captured step)"""
+        key = tuple(int(v) for v in values)
+        if key not in self._idx_cache:
+            self._idx_cache[key] = torch.tensor(key, dtype=torch.int64, device=self.device)
+        return self._idx_cache[key]
 
     # ------------------------------------------------------------------ state (drag_pose.py:47-64)
     def set_initial_state(self, latent, init_global_pos, initial_global_rot, initial_heights):
@@ -61,13 +69,14 @@ class DragPose:
         if self.current_index != 0 or self.temporal is None:  # no predictor: the buffer stays zero, use lambda_temporal = 0
             return
         idx = self.temporal_frames_index
+        idx_t = self._index(idx)
         with torch.no_grad():
-            input_latent = self.latent_buffer[:, idx][:, :-1].clone()
+            input_latent = self.latent_buffer.index_select(1, idx_t)[:, :-1].clone()
             input_disp = torch.stack([self.displacement_buffer[:, j:j + SAMPLE_STEP].sum(dim=1) for j in idx[:-1]], dim=1)
             tgt = self.latent_buffer[:, idx[-1]].unsqueeze(1).clone()
             input_latent = (input_latent - self.means_latent) / self.stds_latent
             tgt = (tgt - self.means_latent) / self.stds_latent
-            heights = self.heights_buffer[:, idx][:, :-1].clone()
+            heights = self.heights_buffer.index_select(1, idx_t)[:, :-1].clone()
             enc_in = torch.cat((input_latent, input_disp, heights), dim=-1)
             buf = self.target_latent_buffer
             for i in range(0, window + 1, SAMPLE_STEP):
@@ -105,7 +114,10 @@ class DragPose:
         tgt_rot = torch.zeros(S, NJ, 9, device=dev)
         w = torch.zeros(S, NJ, 2, device=dev)
         tracked = torch.zeros(S, NJ, dtype=torch.uint8, device=dev)
-        tgt_pos[:, mj], tgt_rot[:, mj], w[:, mj], tracked[:, mj] = tp, tR, wj, 1
+        tgt_pos.index_copy_(1, mj, tp)
+        tgt_rot.index_copy_(1, mj, tR)
+        w.index_copy_(1, mj, wj.unsqueeze(0).expand(S, -1, -1).contiguous())
+        tracked.index_fill_(1, mj, 1)
 
         out = self.opt.optimize(self.latent.contiguous(), target_latent, self.current_global_rot.contiguous(), tgt_pos, tgt_rot,
                                 w, tracked, n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot),
@@ -129,7 +141,7 @@ class DragPose:
             displacement = displacement + adj
         self.latent_buffer = torch.cat((self.latent_buffer[:, 1:], out["z_pre"].unsqueeze(1)), dim=1)
         self.displacement_buffer = torch.cat((self.displacement_buffer[:, 1:], displacement.unsqueeze(1)), dim=1)
-        heights = (out["pos"] + self.current_global_pos.unsqueeze(1))[:, list(height_indices), 1]
+        heights = (out["pos"] + self.current_global_pos.unsqueeze(1)).index_select(1, self._index(height_indices))[:, :, 1]
         self.heights_buffer = torch.cat((self.heights_buffer[:, 1:], heights.unsqueeze(1)), dim=1)
         pose = out["pose"].clone()
         pose[:, :4] = (self.current_global_rot - self.means_q[:4]) / self.stds_q[:4]
