@@ -77,7 +77,8 @@ def test_item_table_and_skeleton_validation():
     import kernel_emu as KE
 
     hm = HostModel()
-    _, _, items = KE.host_tables(hm)
+    _, _, items, smask = KE.host_tables(hm)
+    assert 0 < bin(int(smask[3, KE.G_B2])).count("1") <= 26 and smask[7, KE.G_B1] == 0  # structural-zero step masks
     kinds = list(items["kind"])
     assert kinds[0] == 1 and kinds[1:22] == [0] * 21 and kinds[22] == 2
     assert kinds[23:25] == [3, 3] and list(items["src_quad"][23:25]) == [11, 11]  # joint 11's extra children
