@@ -51,6 +51,18 @@ def synth_on_device(opt, B, seed, device):
                 w=w, tracked=tracked)
 
 
+def pmc_traffic_bytes(frames, iters):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_per_launch.json: separate
+    --pmc runs of this very command).  FETCH_SIZE under-counts reads 2x on gfx950 (MI355X_MICROARCH.md, HBM);
+    both counters are in KB.  Only valid for the configuration the counters were collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")
+    if frames != 4096 or iters != 50 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        c = json.load(f)
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(batch_np, n_iter, budget_s=20.0):
     """The oracle ("port") timed on this host: reference-shaped B=1 autograd + torch.optim.Adam
     loop, 1 thread, on a bounded sample of the same workload."""
@@ -178,7 +190,8 @@ def main():
                                    f"(BASELINE north_star: 4096-frame batch)",
                        "frames_per_gpu": B, "iters": N, "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(B, N),
+                         "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch.json; algorithmic 9.53e6",
                          "kernel": "dp_optimize_kernel", "kernel_ms": kern_ms,
                          "flop_per_launch": B * N * FLOP_PER_FRAME_ITER,
                          "hbm_algorithmic_GBps": B * 1264 / (kern_ms * 1e-3) / 1e9},
