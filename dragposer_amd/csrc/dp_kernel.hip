@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             const f4 acc = mfma_chain<16>(w, b, mk_l2, f4{0.f, 0.f, 0.f, 0.f});
             *(f4*)(yr + 16 * wave + 4 * h) = acc;
         } else {
-            const int half = (wave >> 1) & 1;
+            const int half = l2_half(wave);
             float b[8], w[8];
             load_b<8>(a1r, hs, L2_HALF_STEPS * half, b);
 #pragma unroll
@@ -389,6 +389,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
         // ================= P3: normalise, FK, loss, backward to gy   (wave-private rows)
         {
+#ifdef DP_P3_STAGGER
+            if (wave >= 4) __builtin_amdgcn_s_sleep(DP_P3_STAGGER); // de-phase the two waves of a SIMD (same program, same stalls)
+#endif
             const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
             if (DBG_DUMP && a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
             const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);

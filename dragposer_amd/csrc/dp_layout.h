@@ -55,7 +55,11 @@ DP_HD constexpr int wave_tile(int g, int w) {
     if (g == G_L2) return w < 4 ? w : L2_SPLIT_TILE0 + (w & 1);
     return w < G_NT[g] ? w : -1;
 }
-DP_HD constexpr int wave_step0(int g, int w) { return (g == G_L2 && w >= 6) ? L2_HALF_STEPS : 0; }
+// K-half of the split tiles: tile 4 -> waves 6 (half 0), 4 (half 1); tile 5 -> waves 5 (half 0), 7 (half 1).  With the
+// shipped model's zero-block pattern this pairs the long halves with the short full tiles on each SIMD
+// (SIMD = wave % 4: 7+8, 8+4, 13+2, 9+5 masked steps instead of 7+2, 8+4, 13+8, 9+5).
+DP_HD constexpr int l2_half(int w) { return ((w >> 1) & 1) ^ ((w & 1) ? 0 : 1); }
+DP_HD constexpr int wave_step0(int g, int w) { return (g == G_L2 && w >= 4) ? L2_HALF_STEPS * l2_half(w) : 0; }
 DP_HD constexpr int wave_nsteps(int g, int w) {
     if (g == G_L2) return w < 4 ? G_NS[G_L2] : L2_HALF_STEPS;
     return w < G_NT[g] ? G_NS[g] : 0;

@@ -132,7 +132,7 @@ def emulate_iteration(tables, z, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, l
     for wv in range(4):
         store_tile(yp[0], wv, chain(wf, wv, W_OFF["L2"], load_b(a1, 0, 16), smask[wv, G_L2]))
     for wv in range(4, 8):
-        half = (wv >> 1) & 1
+        half = ((wv >> 1) & 1) ^ (0 if wv & 1 else 1)  # dp_layout.h: l2_half
         store_tile(yp[half], 4 + (wv & 1), chain(wf, wv, W_OFF["L2"], load_b(a1, 8 * half, 8), smask[wv, G_L2]))
     ysum = yp[0] + yp[1]
     # ---- P3 per frame, per item
