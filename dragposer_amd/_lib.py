@@ -67,7 +67,7 @@ class DpResult(C.Structure):
 # every symbol include/dragposer.h declares (checked by tests/test_abi.py)
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
-    "dp_forward", "dp_kernel_geometry",
+    "dp_forward", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
 )
 
 _lib = None

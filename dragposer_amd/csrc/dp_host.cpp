@@ -325,6 +325,43 @@ extern "C" int dp_destroy(dp_ctx* ctx)
     return DP_OK;
 }
 
+extern "C" int dp_io_alloc(dp_ctx* ctx, unsigned long long bytes, void** dev_ptr)
+{
+    if (!ctx || !dev_ptr) return DP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(dev_ptr, bytes));
+    HIP_TRY(ctx, hipMemset(*dev_ptr, 0, bytes));
+    return DP_OK;
+}
+
+extern "C" int dp_io_free(dp_ctx* ctx, void* dev_ptr)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    HIP_TRY(ctx, hipFree(dev_ptr));
+    return DP_OK;
+}
+
+extern "C" int dp_io_upload(dp_ctx* ctx, void* dev_dst, const void* host_src, unsigned long long bytes, void* stream)
+{
+    if (!ctx || !dev_dst || !host_src) return DP_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return DP_OK;
+}
+
+extern "C" int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, unsigned long long bytes, void* stream)
+{
+    if (!ctx || !host_dst || !dev_src) return DP_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return DP_OK;
+}
+
+extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return DP_OK;
+}
+
 extern "C" int dp_kernel_geometry(const dp_ctx*, int* frames_per_block, int* threads_per_block, int* lds_bytes)
 {
     if (frames_per_block) *frames_per_block = FPB;

@@ -36,7 +36,7 @@ extern "C" {
 #define DP_NUM_JOINTS 22
 #define DP_LATENT 24
 #define DP_POSE_CHANNELS 88 /* 22 joints x 4 quaternion channels */
-#define DP_MAX_ITERS 512
+#define DP_MAX_ITERS 256
 
 typedef enum dp_status {
     DP_OK = 0,
@@ -131,6 +131,15 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* params, const 
 
 /* decode + FK only; `out` fields z, z_pre, loss, iters are ignored. */
 int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float* cur_rot, const dp_result* out, void* hip_stream);
+
+/* Device-buffer helpers for callers that have no HIP binding of their own (the native Unity drop-in,
+ * include/dragposer_unity.h).  Thin wrappers over hipMalloc / hipFree / hipMemcpyAsync / hipStreamSynchronize on the
+ * context's device; PyTorch callers never need them. */
+int dp_io_alloc(dp_ctx* ctx, unsigned long long bytes, void** dev_ptr);
+int dp_io_free(dp_ctx* ctx, void* dev_ptr);
+int dp_io_upload(dp_ctx* ctx, void* dev_dst, const void* host_src, unsigned long long bytes, void* hip_stream);
+int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, unsigned long long bytes, void* hip_stream);
+int dp_stream_sync(dp_ctx* ctx, void* hip_stream);
 
 /* introspection for the benchmark: frames per workgroup and workgroup size of the optimise kernel */
 int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes);

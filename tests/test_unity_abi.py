@@ -1,0 +1,131 @@
+"""The native drop-in for the reference's Unity plugin ABI (DragPoserDLL/exportFunc.h:61-70): libDragPoserDLL.so.
+CPU: the ten symbols exist and the host-only steps (BVH skeleton, model file, encoder) work / fail loudly.
+GPU: drag_pose() frame by frame against the Python operator driven with the same targets."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "dragposer_amd", "lib", "libDragPoserDLL.so")
+CLIP = os.path.join(ROOT, "tests", "data", "example_clip.bvh")
+DATA = os.path.join(ROOT, "dragposer_amd", "data")
+TEN = ("init_drag_poser", "set_reference_skeleton", "load_models", "set_mask_and_weights", "init_drag_model", "set_optim_params",
+       "set_lambdas", "set_global_pos", "drag_pose", "destroy_drag_poser")
+
+
+class F3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class F2(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class Qt(C.Structure):
+    _fields_ = [("w", C.c_float), ("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+def _load():
+    import dragposer_amd._lib as L
+
+    L.load()  # pins torch's HIP runtime first
+    lib = C.CDLL(LIB)
+    lib.init_drag_poser.restype = C.c_void_p
+    lib.drag_poser_last_error.restype = C.c_char_p
+    lib.drag_poser_last_error.argtypes = [C.c_void_p]
+    lib.set_reference_skeleton.argtypes = [C.c_void_p, C.c_char_p]
+    lib.load_models.argtypes = [C.c_void_p, C.c_char_p]
+    lib.set_mask_and_weights.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(F2)]
+    lib.init_drag_model.argtypes = [C.c_void_p, F3, Qt]
+    lib.set_optim_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_float]
+    lib.set_lambdas.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+    lib.set_global_pos.argtypes = [C.c_void_p, F3]
+    lib.drag_pose.argtypes = [C.c_void_p, C.c_int, C.POINTER(F3), C.POINTER(Qt), C.POINTER(Qt), C.POINTER(F3)]
+    lib.destroy_drag_poser.argtypes = [C.c_void_p]
+    lib.drag_poser_last_iterations.argtypes = [C.c_void_p]
+    lib.drag_poser_get_latent.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.drag_poser_set_latent.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    return lib
+
+
+def test_exports_the_ten_reference_functions_and_fails_loudly():
+    lib = _load()
+    for sym in TEN:
+        assert hasattr(lib, sym), sym
+    h = lib.init_drag_poser()
+    lib.load_models(h, DATA.encode())  # before the skeleton
+    assert b"set_reference_skeleton" in lib.drag_poser_last_error(h)
+    lib.set_reference_skeleton(h, b"/nonexistent.bvh")
+    assert b"cannot open" in lib.drag_poser_last_error(h)
+    lib.set_reference_skeleton(h, CLIP.encode())
+    assert lib.drag_poser_last_error(h) == b""
+    if not torch.cuda.is_available():
+        lib.load_models(h, DATA.encode())
+        assert b"no HIP device" in lib.drag_poser_last_error(h)  # no CPU fallback here either
+    lib.destroy_drag_poser(h)
+
+
+@pytest.mark.gpu
+def test_drag_pose_matches_python_operator():
+    from dragposer_amd import quat_np as Q
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    lib = _load()
+    h = lib.init_drag_poser()
+    lib.set_reference_skeleton(h, CLIP.encode())
+    lib.load_models(h, DATA.encode())
+    assert lib.drag_poser_last_error(h) == b"", lib.drag_poser_last_error(h)
+    mask = np.zeros(22, np.float32)
+    mask[R.TRACK6] = 1
+    w = np.ones((22, 2), np.float32)
+    for j, wj in R.W6.items():
+        w[j] = wj
+    lib.set_mask_and_weights(h, mask.ctypes.data_as(C.POINTER(C.c_float)), w.ctypes.data_as(C.POINTER(F2)))
+    lib.set_optim_params(h, 1e-4, 1e-2, 10, 1e-2)  # Unity default budget: 10 iterations (Core/DragPoser.cs:34)
+    lib.set_lambdas(h, 1.0, 0.0, 0)
+    m = R.OracleModel()
+    b = R.synth_inputs(m, 12, seed=5)  # 12 unrelated target frames, fed as a sequence
+    cr0 = b["cur_rot"][0]
+    lib.init_drag_model(h, F3(0.1, 0.2, 0.3), Qt(*[float(v) for v in cr0]))
+    z0 = np.zeros(24, np.float32)
+    lib.drag_poser_get_latent(h, z0.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.abs(z0).max() > 0 and np.isfinite(z0).all()
+
+    opt = LatentOptimizer(device="cuda:0")
+    dp = DragPose(opt, None, np.zeros(24), np.ones(24), 1)
+    dp.set_initial_state(z0, np.array([0.1, 0.2, 0.3], np.float32), cr0, np.zeros(6))
+    idx = np.array(R.TRACK6)
+    wj = np.array([R.W6[j] for j in R.TRACK6], np.float32)
+    raw = np.load(R.DEFAULT_MODEL)
+    for t in range(12):
+        tp = b["tgt_pos"][t, idx]
+        tR = b["tgt_rot"][t, idx].reshape(6, 3, 3)
+        # rotation targets as quaternions (the plugin converts them back with to_matrix, run_drag.py:136)
+        tq = np.stack([_mat_to_quat(M) for M in tR])
+        res_pose = (Qt * 22)()
+        res_pos = (F3 * 1)()
+        lib.drag_pose(h, 6, (F3 * 6)(*[F3(*map(float, p)) for p in tp]), (Qt * 6)(*[Qt(*map(float, q)) for q in tq]), res_pose, res_pos)
+        assert lib.drag_poser_last_error(h) == b""
+        pose, gpos = dp.run(torch.tensor(tp), torch.tensor(Q.to_matrix(tq).astype(np.float32)), idx, wj, stop_eps_pos=1e-4, stop_eps_rot=1e-2,
+                            max_iter=10, learning_rate=1e-2, lambda_rot=1.0, lambda_temporal=0.0, temporal_future_window=0)
+        assert lib.drag_poser_last_iterations(h) == int(dp.last["iters"][0])
+        np.testing.assert_allclose([res_pos[0].x, res_pos[0].y, res_pos[0].z], gpos.cpu().numpy(), atol=1e-6)
+        qs = (pose.cpu().numpy().astype(np.float64) * opt.host_model.arrays["std_q"] + opt.host_model.arrays["mean_q"]).reshape(1, 22, 4)
+        local = Q.from_root_space(qs, raw["parents"])[0]
+        got = np.array([[q.w, q.x, q.y, q.z] for q in res_pose])
+        np.testing.assert_allclose(got, local, atol=2e-6)
+    lib.destroy_drag_poser(h)
+
+
+def _mat_to_quat(M):
+    w = np.sqrt(max(0.0, 1 + M[0, 0] + M[1, 1] + M[2, 2])) / 2
+    x = np.sqrt(max(0.0, 1 + M[0, 0] - M[1, 1] - M[2, 2])) / 2
+    y = np.sqrt(max(0.0, 1 - M[0, 0] + M[1, 1] - M[2, 2])) / 2
+    z = np.sqrt(max(0.0, 1 - M[0, 0] - M[1, 1] + M[2, 2])) / 2
+    return np.array([w, np.copysign(x, M[2, 1] - M[1, 2]), np.copysign(y, M[0, 2] - M[2, 0]), np.copysign(z, M[1, 0] - M[0, 1])])
