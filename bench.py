@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--max-trackers", type=int, default=6,
+                    help="tracker-count bound handed to dp_optimize (the workload has 6); 0 = no hint -> 8-wave kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -130,7 +132,7 @@ def main():
     B, N = args.frames, args.iters
     batch = synth_on_device(opt, B, 1234 + rank, device)
     names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
-    out = opt.optimize(**batch, n_iter=N, outputs=names)
+    out = opt.optimize(**batch, n_iter=N, outputs=names, max_trackers=args.max_trackers)
     torch.cuda.synchronize()
 
     def barrier():
@@ -138,19 +140,20 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out, max_trackers=args.max_trackers)
     barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream the kernel is launched on
     for _ in range(args.steps):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out, max_trackers=args.max_trackers)
     ev1.record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
+    fpb, tpb, lds_bytes = opt.kernel_geometry()
 
     # ---- parity on a sample (rank-local), reduced with the timing
     err_mm = float("nan")
@@ -192,7 +195,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(B, N),
                          "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch.json; algorithmic 9.53e6",
-                         "kernel": "dp_optimize_kernel", "kernel_ms": kern_ms,
+                         "kernel": "dp_optimize_kernel" if tpb == 512 else f"dp_optimize_kernel4<{fpb // 8}>", "kernel_ms": kern_ms,
+                         "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},
                          "flop_per_launch": B * N * FLOP_PER_FRAME_ITER,
                          "hbm_algorithmic_GBps": B * 1264 / (kern_ms * 1e-3) / 1e9},
             "parity_p99_mm_vs_oracle": err_mm,  # 256 frames x 22 joints vs the C oracle (fp32)

@@ -52,7 +52,7 @@ class DpParams(C.Structure):
     _fields_ = [
         ("n_iter", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("lambda_rot", C.c_float), ("lambda_tmp", C.c_float), ("early_stop", C.c_int),
-        ("stop_eps_pos", C.c_float), ("stop_eps_rot", C.c_float), ("min_loss_incr", C.c_float),
+        ("stop_eps_pos", C.c_float), ("stop_eps_rot", C.c_float), ("min_loss_incr", C.c_float), ("max_trackers", C.c_int),
     ]
 
 

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,12 +16,14 @@ using namespace dpl;
 
 struct dp_ctx {
     int device = -1;
+    int n_cu = 256;
     float* d_wfrag = nullptr;
     float* d_bias = nullptr;
     ItemConst* d_items = nullptr;
     dp_folded folded;
     std::vector<unsigned> smask;
     std::string err;
+    int last_kernel = 0; // 8, 41 (4 waves x 8 frames) or 42 (4 waves x 16 frames): what the last launch used
 };
 
 static thread_local std::string g_create_err;
@@ -288,6 +291,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
 
     dp_ctx* ctx = new dp_ctx();
     ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = dp_fold_decoder(model, &ctx->folded);
     std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
     ctx->smask.assign(NWAVE * NGEMM, 0u);
@@ -362,11 +366,12 @@ extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
     return DP_OK;
 }
 
-extern "C" int dp_kernel_geometry(const dp_ctx*, int* frames_per_block, int* threads_per_block, int* lds_bytes)
-{
-    if (frames_per_block) *frames_per_block = FPB;
-    if (threads_per_block) *threads_per_block = NTHREADS;
-    if (lds_bytes) *lds_bytes = dp_kernel_lds_bytes();
+extern "C" int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes)
+{ // of the kernel the context's last launch used (the 8-wave kernel before any launch)
+    const int k = ctx ? ctx->last_kernel : 0;
+    if (frames_per_block) *frames_per_block = k == 41 ? 8 : FPB;
+    if (threads_per_block) *threads_per_block = (k == 41 || k == 42) ? 256 : NTHREADS;
+    if (lds_bytes) *lds_bytes = (k == 41 || k == 42) ? dp_kernel4_lds_bytes() : dp_kernel_lds_bytes();
     return DP_OK;
 }
 
@@ -386,9 +391,29 @@ static void fill_results(const dp_result* out, KArgs& k)
     k.world_rot = out->world_rot; k.pos = out->pos; k.rot = out->rot; k.loss = out->loss; k.iters = out->iters;
 }
 
-static int launch(dp_ctx* ctx, KArgs& k, void* stream)
+// Which kernel runs a batch (both give bit-identical results):
+//   dp_kernel.hip   8 waves, 16 frames per workgroup, one workgroup per CU -- early stop, unknown / large tracker counts
+//   dp_kernel4.hip  4 waves, two workgroups per CU; needs the caller's max_trackers hint (<= its capacity);
+//                   8-frame groups while the batch leaves CUs idle or single-occupied, 16-frame groups beyond that.
+// DP_KERNEL=8|4x1|4x2 in the environment overrides the choice (benchmarks, tests).
+static int pick_kernel(const dp_ctx* ctx, const KArgs& k, int max_trackers)
 {
-    hipError_t e = dp_launch_optimize(&k, (hipStream_t)stream);
+    int choice = 8;
+    const bool k4_ok = !k.early_stop && (k.mode == 1 || (max_trackers > 0 && max_trackers <= dp_kernel4_max_trackers()));
+    if (k4_ok) choice = (k.n_frames > 16 * ctx->n_cu) ? 42 : 41;
+    if (const char* e = std::getenv("DP_KERNEL")) {
+        if (!std::strcmp(e, "8")) choice = 8;
+        else if (k4_ok && !std::strcmp(e, "4x1")) choice = 41;
+        else if (k4_ok && !std::strcmp(e, "4x2")) choice = 42;
+    }
+    return choice;
+}
+
+static int launch(dp_ctx* ctx, KArgs& k, void* stream, int max_trackers = 0)
+{
+    const int choice = pick_kernel(ctx, k, max_trackers);
+    ctx->last_kernel = choice;
+    hipError_t e = choice == 8 ? dp_launch_optimize(&k, (hipStream_t)stream) : dp_launch_optimize4(&k, choice - 40, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
     return DP_OK;
 }
@@ -425,7 +450,7 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
         k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
     }
-    return launch(ctx, k, stream);
+    return launch(ctx, k, stream, p->max_trackers);
 }
 
 extern "C" int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, void* stream)

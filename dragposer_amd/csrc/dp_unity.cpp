@@ -297,6 +297,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     p.n_iter = d->max_iter; p.lr = d->lr; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f;
     p.lambda_rot = d->lambda_rot; p.lambda_tmp = 0.f;
     p.early_stop = 1; p.stop_eps_pos = d->stop_eps_pos; p.stop_eps_rot = d->stop_eps_rot; p.min_loss_incr = 0.00001f; // run() default
+    p.max_trackers = 0;
     dp_result r;
     std::memset(&r, 0, sizeof(r));
     r.z = dout + OUT_Z; r.z_pre = dout + OUT_ZPRE; r.pose = dout + OUT_POSE; r.disp = dout + OUT_DISP; r.world_disp = dout + OUT_WD;

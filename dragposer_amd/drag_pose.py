@@ -122,7 +122,7 @@ class DragPose:
         out = self.opt.optimize(self.latent.contiguous(), target_latent, self.current_global_rot.contiguous(), tgt_pos, tgt_rot,
                                 w, tracked, n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot),
                                 lambda_tmp=float(lambda_temporal), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
-                                min_loss_incr=min_loss_incr)
+                                min_loss_incr=min_loss_incr, max_trackers=E)
         self.last = out
         self.latent = out["z"]
         if verbose:

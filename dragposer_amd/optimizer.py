@@ -60,6 +60,12 @@ class LatentOptimizer:
         self.lib.dp_kernel_geometry(self.ctx, C.byref(fpb), C.byref(tpb), C.byref(lds))
         self.frames_per_block, self.threads_per_block, self.lds_bytes = fpb.value, tpb.value, lds.value
 
+    def kernel_geometry(self):
+        """(frames per workgroup, threads per workgroup, LDS bytes) of the kernel the last launch used"""
+        fpb, tpb, lds = C.c_int(), C.c_int(), C.c_int()
+        self.lib.dp_kernel_geometry(self.ctx, C.byref(fpb), C.byref(tpb), C.byref(lds))
+        return fpb.value, tpb.value, lds.value
+
     def close(self):
         if getattr(self, "ctx", None) is not None and self.ctx.value:
             self.lib.dp_destroy(self.ctx)
@@ -86,12 +92,14 @@ class LatentOptimizer:
 
     def optimize(self, z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter=50, lr=1e-2, betas=(0.9, 0.999),
                  eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=None,
-                 outputs=None, out=None, _debug=None):
+                 max_trackers=0, outputs=None, out=None, _debug=None):
         """All inputs are device tensors: z0/z_tgt [B,24], cur_rot [B,4], tgt_pos [B,22,3],
         tgt_rot [B,22,9], w [B,22,2] (fp32) and tracked [B,22] (uint8).  Returns a dict of device
         tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream.
         With stop_eps_* > 0 or min_loss_incr given, every frame runs the reference's own while-condition
-        (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter)."""
+        (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter).
+        `max_trackers`: upper bound of tracked joints per frame when the caller knows it (0 = unknown); lets the
+        library pick its two-workgroups-per-CU kernel for fixed-iteration runs (same results)."""
         B = int(z0.shape[0])
         dev = self.device
         batch = _lib.DpBatch()
@@ -106,7 +114,8 @@ class LatentOptimizer:
         early = min_loss_incr is not None or stop_eps_pos > 0 or stop_eps_rot > 0
         p = _lib.DpParams(n_iter=int(n_iter), lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, lambda_rot=lambda_rot,
                           lambda_tmp=lambda_tmp, early_stop=int(early), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
-                          min_loss_incr=float("-inf") if min_loss_incr is None else min_loss_incr)
+                          min_loss_incr=float("-inf") if min_loss_incr is None else min_loss_incr,
+                          max_trackers=int(max_trackers))
         names = tuple(outputs) if outputs is not None else tuple(_OUT_SPECS)
         res, tensors = self._outputs(B, names, out)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -101,6 +101,10 @@ typedef struct dp_params {
     float lambda_rot, lambda_tmp;
     int early_stop;    /* 1: per-frame while-condition of drag_pose.py:300-304 */
     float stop_eps_pos, stop_eps_rot, min_loss_incr;
+    int max_trackers;  /* hint: upper bound of tracked joints in any frame of the batch (the reference's len(mask_joints),
+                          drag_pose.py:116), or 0 when unknown.  With 1..16 and early_stop == 0 the launch uses the
+                          two-workgroups-per-CU kernel (same results bit for bit, higher throughput); trackers beyond a
+                          stated bound are ignored.  0 is always safe. */
 } dp_params;
 
 /* Outputs, DEVICE pointers; any may be NULL.  All but z are those of the LAST forward pass
@@ -141,7 +145,8 @@ int dp_io_upload(dp_ctx* ctx, void* dev_dst, const void* host_src, unsigned long
 int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, unsigned long long bytes, void* hip_stream);
 int dp_stream_sync(dp_ctx* ctx, void* hip_stream);
 
-/* introspection for the benchmark: frames per workgroup and workgroup size of the optimise kernel */
+/* introspection for the benchmark: frames per workgroup, workgroup size and LDS bytes of the kernel the context's
+ * last dp_optimize / dp_forward launch used */
 int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes);
 
 #ifdef __cplusplus

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header_sizes():
     ptr = C.sizeof(C.c_void_p)
     assert C.sizeof(_lib.DpModel) == 20 * ptr + 8  # 20 pointers + int (+pad)
     assert C.sizeof(_lib.DpBatch) == 8 + 7 * ptr
-    assert C.sizeof(_lib.DpParams) == 11 * 4
+    assert C.sizeof(_lib.DpParams) == 12 * 4
     assert C.sizeof(_lib.DpResult) == 10 * ptr
     assert C.sizeof(_lib.DpFolded) == 4 * (40 * 24 + 40 + 60 * 40 + 60 + 92 * 60 + 92)
 

@@ -14,16 +14,19 @@ from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
 NAMES = ["L0 mfma", "bar1", "L1 load+mfma", "bar2", "L2 load+mfma", "bar3", "P3a normalise/bones", "P3b tracker terms",
          "P3c gather/backward/out", "bar4", "bL2", "bar5", "bL1", "bar6", "bL0", "bar7", "Adam"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+MAXT = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # tracker hint: > 0 selects dp_kernel4 (DP_KERNEL=4x1|4x2 forces a variant)
 N = 50
 dev = torch.device("cuda:0")
 opt = LatentOptimizer(device=dev)
 b = R.synth_inputs(R.OracleModel(), B)
 d = to_device_batch(b, dev)
-grid = (B + 15) // 16
-dbg = torch.zeros(grid * 40 + 64, device=dev)
+dbg = torch.zeros(((B + 7) // 8) * 40 + 64, device=dev)
 for _ in range(3):
-    opt.optimize(**d, n_iter=N, _debug=dbg)
+    opt.optimize(**d, n_iter=N, max_trackers=MAXT, _debug=dbg)
 torch.cuda.synchronize()
+fpb, tpb, _ = opt.kernel_geometry()
+grid = (B + fpb - 1) // fpb
+print(f"kernel: {fpb} frames / {tpb} threads per workgroup, {grid} workgroups")
 p = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20)[:, :17].astype(np.float64) / N
 tot = p.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
