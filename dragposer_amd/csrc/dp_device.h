@@ -13,21 +13,41 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Diagnostic build (-DDP_PROFILE): wave 0 of every workgroup accumulates s_memtime deltas per phase
 // and stores 20 x u64 per workgroup into the debug buffer.  Never part of the shipped library.
+struct Prof {
 #ifdef DP_PROFILE
-#define STAMP(i)                                                     \
-    do {                                                             \
-        __builtin_amdgcn_sched_barrier(0);                           \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-        prof[i] += t_ - tprev;                                       \
-        tprev = t_;                                                  \
-        __builtin_amdgcn_sched_barrier(0);                           \
-    } while (0)
+    unsigned long long t[20], prev;
+    DEV void start()
+    {
+        for (int i = 0; i < 20; ++i) t[i] = 0;
+        prev = __builtin_amdgcn_s_memtime();
+    }
+    DEV void stamp(int i)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        t[i] += now - prev;
+        prev = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    DEV void store(float* dbg, int tid, int block)
+    {
+        if (dbg && tid == 0) {
+            unsigned long long* o = (unsigned long long*)dbg + (size_t)block * 20;
+            for (int i = 0; i < 20; ++i) o[i] = t[i];
+        }
+    }
+#else
+    DEV void start() {}
+    DEV void stamp(int) {}
+    DEV void store(float*, int, int) {}
+#endif
+};
+#ifdef DP_PROFILE
 #define DBG_DUMP 0
 #else
-#define STAMP(i)
 #define DBG_DUMP 1
 #endif
-
+#define STAMP(i) prof.stamp(i)
 
 DEV f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 

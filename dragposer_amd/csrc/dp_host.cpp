@@ -391,16 +391,18 @@ static void fill_results(const dp_result* out, KArgs& k)
     k.world_rot = out->world_rot; k.pos = out->pos; k.rot = out->rot; k.loss = out->loss; k.iters = out->iters;
 }
 
-// Which kernel runs a batch (both give bit-identical results):
-//   dp_kernel.hip   8 waves, 16 frames per workgroup, one workgroup per CU -- early stop, unknown / large tracker counts
-//   dp_kernel4.hip  4 waves, two workgroups per CU; needs the caller's max_trackers hint (<= its capacity);
-//                   8-frame groups while the batch leaves CUs idle or single-occupied, 16-frame groups beyond that.
-// DP_KERNEL=8|4x1|4x2 in the environment overrides the choice (benchmarks, tests).
+// Which kernel runs a batch (all give bit-identical results):
+//   dp_kernel.hip   8 waves, 16 frames per workgroup, one workgroup per CU -- the default
+//   dp_kernel4.hip  4 waves, 16 frames per workgroup, two workgroups per CU: a few percent more throughput once every
+//                   CU has at least two workgroups (measured +2 % at 8192 frames, +8 % at 65536); needs the caller's
+//                   max_trackers hint (<= its capacity) and a fixed iteration count.
+// DP_KERNEL=8|4x2|4x1 in the environment overrides the choice for experiments (4x1: 8-frame groups, measured slower
+// at every batch size -- the kinematics phase is bound by per-wave instruction issue, not by frames per wave).
 static int pick_kernel(const dp_ctx* ctx, const KArgs& k, int max_trackers)
 {
     int choice = 8;
     const bool k4_ok = !k.early_stop && (k.mode == 1 || (max_trackers > 0 && max_trackers <= dp_kernel4_max_trackers()));
-    if (k4_ok) choice = (k.n_frames > 16 * ctx->n_cu) ? 42 : 41;
+    if (k4_ok && k.n_frames > 16 * ctx->n_cu) choice = 42;
     if (const char* e = std::getenv("DP_KERNEL")) {
         if (!std::strcmp(e, "8")) choice = 8;
         else if (k4_ok && !std::strcmp(e, "4x1")) choice = 41;

@@ -17,7 +17,7 @@
 //     gradients) goes through wave-private LDS rows, so P3 needs no workgroup barrier inside.
 //   * bL0 and Adam are fused: the two waves that produce dL/dz own z, m, v in registers.
 // 7 workgroup barriers per iteration, no global memory traffic inside the loop.
-#include "dp_device.h"
+#include "dp_p3.h"
 
 // ------------------------------------------------------------------------------------------------
 // LDS map (floats)
@@ -28,12 +28,13 @@ constexpr int L_GY = L_A1 + FPB * S_A1;            // gy [16][S_Y]      dL/dy qu
 constexpr int L_Y = L_GY + FPB * S_Y;              // y  [2][16][S_Y]   plane 1: 2nd K-half of tiles 4,5 (kept for the epilogue)
 constexpr int L_ZERO0 = L_Y + FPB * S_Y;           // ---- everything from here on is zeroed at start (incl. y plane 1)
 constexpr int L_BONE = L_ZERO0 + FPB * S_Y;        // bone[16][32][4]
-constexpr int L_GPC = L_BONE + FPB * 32 * 4;       // gpc [16][24][4]  tracker position gradients by rank
-constexpr int L_CQ = L_GPC + FPB * 24 * 4;         // cq  [16][24][4]  tracker contributions to d/d(qw)
-constexpr int L_LP = L_CQ + FPB * 24 * 4;          // lp  [16][24][2]  tracker loss terms
-constexpr int L_QD = L_LP + FPB * 24 * 2;          // qd  [16][20]     qw[4] | d[3],0 | R0 rows (3 x [3],0)
-constexpr int L_TRK = L_QD + FPB * 20;             // tracker inputs, SoA: [16 frames][4 quads][24 joints][4]
-constexpr int L_ITEM = L_TRK + FPB * 24 * 16;      // item constants, SoA: sd[32][4] | mu[32][4] | child offset[32][4]
+constexpr int R8 = 24;                             // tracker capacity per frame (>= NJ: every joint may carry one)
+constexpr int L_GPC = L_BONE + FPB * 32 * 4;       // gpc [16][R8][4]  tracker position gradients by rank
+constexpr int L_CQ = L_GPC + FPB * R8 * 4;         // cq  [16][R8][4]  tracker contributions to d/d(qw)
+constexpr int L_LP = L_CQ + FPB * R8 * 4;          // lp  [16][R8][2]  tracker loss terms
+constexpr int L_QD = L_LP + FPB * R8 * 2;          // qd  [16][QD_S]   (dp_p3.h)
+constexpr int L_TRK = L_QD + FPB * QD_S;           // tracker inputs by rank: [16 frames][4 quads][R8][4]
+constexpr int L_ITEM = L_TRK + FPB * R8 * 16;      // item constants, SoA: sd[32][4] | mu[32][4] | child offset[32][4]
 constexpr int L_BIAS = L_ITEM + 3 * 32 * 4;        // bias rows of L0 (48) and L1 (64), padded to 64 each
 constexpr int L_ZT = L_BIAS + 128;                 // z_tgt [16][S_Z]
 constexpr int WB_STRIDE = 60;                      // per lane: bL2[26] pad2 | bL1[16] | bL0[10] | pad6
@@ -73,24 +74,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
     float* yr = lds + L_Y + f16 * S_Y;          //                   y plane 0
     const float* gyr = lds + L_GY + f16 * S_Y;  //                   gy
     float* yp = lds + L_Y;
-    float* bone = lds + L_BONE + pf * 128;
-    float* gpc = lds + L_GPC + pf * 96;
-    float* cqb = lds + L_CQ + pf * 96;
-    float* lpb = lds + L_LP + pf * 48;
-    float* qdb = lds + L_QD + pf * 20;
+    const FrameRows<R8> fr = {lds + L_BONE + pf * 128, lds + L_GPC + pf * (4 * R8), lds + L_CQ + pf * (4 * R8),
+                              lds + L_LP + pf * (2 * R8), lds + L_QD + pf * QD_S, lds + L_TRK + pf * (16 * R8)};
     const ItemConst* icg = a.items + it_id;                       // global copy: read once, before the loop
     const float* icl = lds + L_ITEM + 4 * it_id;                  // LDS copy (SoA): sd, +128: mu, +256: child offset
-    const float* tin = lds + L_TRK + (pf * 96 + (it_id < NJ ? it_id : 23)) * 4; // + 96*k floats: k-th quad of TrackIn
     const float* wbl = lds + L_WB + ((wave & 3) * 64 + lane) * WB_STRIDE;
 
     // ---- zero the scratch part of the LDS (incl. plane 1 of y), copy the small tables
     for (int i = tid; i < L_ITEM - L_ZERO0; i += NTHREADS) lds[L_ZERO0 + i] = 0.f;
-    if (tid < 32 * 3) { // item constants: AoS (128 B per item, bank-conflicting) -> three float4 planes
-        const int it = tid & 31, k = tid >> 5;
-        const float* src = (const float*)(a.items + it) + (k == 0 ? 0 : k == 1 ? 4 : 8);
-        *(f4*)(lds + L_ITEM + k * 128 + 4 * it) = f4{src[0], src[1], src[2], k == 2 ? 0.f : src[3]};
-    }
-    if (tid < 128) lds[L_BIAS + tid] = a.bias[tid];
+    stage_item_tables(a, lds + L_ITEM, lds + L_BIAS, tid);
     __syncthreads();
 
     // ---- loop-invariant MFMA A operands: forward weights stay in VGPRs for the whole kernel, the
@@ -126,59 +118,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
 
     // ---- P3 per-lane identity (a few integers stay in registers, the float constants are re-read from
     //      LDS every iteration to keep the register budget for the kinematics temporaries)
-    const int sq = icg->src_quad, dq = icg->dst_quad;
-    const int ch_id = icg->ch_id;
-    const unsigned ch_sub = icg->ch_sub, plo = icg->path_lo, phi = icg->path_hi;
-    const int kind = icg->kind;
-    const bool is_joint = kind == KIND_JOINT || kind == KIND_ROOT; // owns a tracker slot / outputs
-    const bool has_quat = kind != KIND_DISP && kind != KIND_IDLE;
-    const bool is_root = kind == KIND_ROOT;
-    const bool is_disp = kind == KIND_DISP;
+    const ItemId id = load_item(icg);
     const int gfp = blk0 + pf;
-    const int gfc = min(gfp, nB - 1);
     const bool fvalid = gfp < nB;
-    const Q4 cur = {a.cur_rot[gfc * 4 + 0], a.cur_rot[gfc * 4 + 1], a.cur_rot[gfc * 4 + 2], a.cur_rot[gfc * 4 + 3]};
-    bool trk = false;
-    if (optimise && is_joint) trk = a.tracked[gfc * NJ + it_id] != 0;
-    const unsigned long long bal = __ballot(trk);
-    const unsigned tmask = (lane >> 5) ? (unsigned)(bal >> 32) : (unsigned)bal; // tracked joints of my frame
-    const int E = __popc(tmask);
-    const int rank = __popc(tmask & ((1u << it_id) - 1u));
-    const int Emax = max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 32));
-    unsigned sel6 = 0; // bit u: the tracked joint of rank u lies below my child bone (first 6 ranks, loop-invariant)
-    {
-        unsigned m = tmask;
-        for (int u = 0; u < 6; ++u) {
-            const int t = __builtin_ctz(m | 0x80000000u);
-            m &= m - 1u;
-            sel6 |= ((ch_sub >> t) & 1u) << u;
-        }
-    }
-    if (trk) {
-        const float invE = 1.f / (float)E;
-        const float* p = a.tgt_pos + (size_t)(gfc * NJ + it_id) * 3;
-        const float* r = a.tgt_rot + (size_t)(gfc * NJ + it_id) * 9;
-        const float wp = a.w[(gfc * NJ + it_id) * 2 + 0], wr = a.w[(gfc * NJ + it_id) * 2 + 1];
-        const float clp = wp * invE * (1.f / 3.f);             // loss_pos coefficient  w_pos / (3E)
-        const float clr = a.lam_rot * wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
-        float* t = lds + L_TRK + (pf * 96 + it_id) * 4;        // TrackIn as four float4 planes (SoA)
-        *(f4*)(t) = f4{p[0], p[1], p[2], 2.f * clp};
-        *(f4*)(t + 96) = f4{r[0], r[1], r[2], r[3]};
-        *(f4*)(t + 192) = f4{r[4], r[5], r[6], r[7]};
-        *(f4*)(t + 288) = f4{r[8], 2.f * clr, clp, clr};
-    }
-    // constant root-frame bones of the root's children
-    if (it_id < MAX_ROOT_CH) *(f4*)(bone + icg->init_id * 4) = f4{icg->init_off[0], icg->init_off[1], icg->init_off[2], 0.f};
+    int Emax;
+    const unsigned pk = p3_setup<R8>(a, icg, id, lane, it_id, min(gfp, nB - 1), optimise, fr, Emax);
 
     f4 a0v = {0.f, 0.f, 0.f, 0.f}, a1v = a0v; // my tile of a0 / a1 (kept for the LeakyReLU derivative)
     float es_prev = 10000000.f; // early stop, root lane: previous total loss (drag_pose.py:297), active flag, count
     bool es_act = true;
     int es_iters = 0;
     __syncthreads();
-#ifdef DP_PROFILE
-    unsigned long long prof[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
-#endif
+    Prof prof;
+    prof.start();
 
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
@@ -236,159 +188,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         __syncthreads();
         STAMP(5);
 
-        // ================= P3: normalise, FK, loss, backward to gy   (wave-private rows)
-        {
-#ifdef DP_P3_STAGGER
-            if (wave >= 4) __builtin_amdgcn_s_sleep(DP_P3_STAGGER); // de-phase the two waves of a SIMD (same program, same stalls)
-#endif
-            const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
-            if (DBG_DUMP && a.dbg && iter == 0 && fvalid && dq == sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * sq) = y4;
-            const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
-            const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
-            const float nn = r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z;
-            const float inv = has_quat ? __builtin_amdgcn_rsqf(nn) : 0.f;
-            const Q4 q = {r.w * inv, r.x * inv, r.y * inv, r.z * inv};
-            M3 M = quat_to_mat(q);
-            if (is_root) {
-                const Q4 qw0 = quat_mul(cur, q);
-                const M3 R = quat_to_mat(qw0); // world root rotation, computed once per frame
-                *(f4*)(qdb) = f4{qw0.w, qw0.x, qw0.y, qw0.z};
-                *(f4*)(qdb + 8) = f4{R.m00, R.m01, R.m02, 0.f};
-                *(f4*)(qdb + 12) = f4{R.m10, R.m11, R.m12, 0.f};
-                *(f4*)(qdb + 16) = f4{R.m20, R.m21, R.m22, 0.f};
-                M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-            }
-            if (is_disp) *(f4*)(qdb + 4) = f4{r.w, r.x, r.y, 0.f};
-            {
-                const f4 cho = *(const f4*)(icl + 256); // child offset (x,y,z)
-                const V3 u = mat_vec(M, V3{cho.x, cho.y, cho.z});
-                *(f4*)(bone + ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
-            }
-            wave_sync();
-            STAMP(6);
-
-            const f4 qwv = *(const f4*)(qdb);
-            const f4 dv = *(const f4*)(qdb + 4);
-            const f4 r0v = *(const f4*)(qdb + 8), r1v = *(const f4*)(qdb + 12), r2v = *(const f4*)(qdb + 16);
-            f4 t0, t1, t2, t3; // tracker inputs of my joint (tracked lanes only)
-            if (trk) {
-                t0 = *(const f4*)(tin);       // tp, cgp
-                t1 = *(const f4*)(tin + 96);  // tR[0..3]
-                t2 = *(const f4*)(tin + 192); // tR[4..7]
-                t3 = *(const f4*)(tin + 288); // tR[8], cgr, clp, clr
-            }
-            const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
-            const M3 R0 = {r0v.x, r0v.y, r0v.z, r1v.x, r1v.y, r1v.z, r2v.x, r2v.y, r2v.z};
-            V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
-            {
-                f4 b[MAX_PATH];
-#pragma unroll
-                for (int i = 0; i < MAX_PATH; ++i) {
-                    const unsigned k = (i < 6) ? ((plo >> (5 * i)) & 31u) : (phi & 31u);
-                    b[i] = *(const f4*)(bone + k * 4);
+        // ================= P3: normalise, FK, loss, backward to gy   (wave-private rows; dp_p3.h)
+        p3_round<R8>(a, id, pk, Emax, icl, yp + pf * S_Y, lds + L_GY + pf * S_Y, pf >= 8, fr, iter, gfp, fvalid, prof, [&]() {
+            if (EARLY) { // root lane: per-frame stop test of the reference's while loop (drag_pose.py:300-304,351-355)
+                const int E = __popc(__float_as_uint(fr.qd[24]));
+                float lp = 0.f, lr = 0.f;
+                for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(fr.lp + e0 * 2); lp += l.x; lr += l.y; }
+                const f4 p0 = *(const f4*)(lds + L_LT + pf * 8);
+                const f2 p1 = *(const f2*)(lds + L_LT + pf * 8 + 4);
+                const float lt = (((p0.x + p0.y) + (p0.z + p0.w)) + (p1.x + p1.y)) * a.lam_tmp * (1.f / 24.f);
+                const float tot = (lp + lr) + lt;
+                const bool cont = (lp > a.stop_eps_pos || lr > a.stop_eps_rot) && (es_prev - tot > a.min_loss_incr) && !last;
+                float* es = lds + L_ES + pf * 8;
+                if (es_act) {
+                    es_prev = tot;
+                    ++es_iters;
+                    *(f4*)(es + 4) = f4{lp, lr, lt, 0.f}; // losses of this frame's last executed iteration
                 }
-#pragma unroll
-                for (int i = 0; i < MAX_PATH; ++i) { pr.x += b[i].x; pr.y += b[i].y; pr.z += b[i].z; }
+                *(f4*)(es) = f4{es_act ? 1.f : 0.f, (es_act && !cont) ? 1.f : 0.f, (float)es_iters, (es_act && cont) ? 1.f : 0.f};
+                es_act = es_act && cont;
             }
-            M3 gM = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (trk) { // tracker terms in the root frame
-                const V3 tp = {t0.x, t0.y, t0.z};
-                const M3 tR = {t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x};
-                const float cgp = t0.w, cgr = t3.y;
-                const V3 tpr = matT_vec(R0, tp);
-                const V3 e = {pr.x - tpr.x, pr.y - tpr.y, pr.z - tpr.z};
-                const V3 gp = {cgp * e.x, cgp * e.y, cgp * e.z};
-                const M3 tRr = matT_mat(R0, tR);
-                const M3 eM = {M.m00 - tRr.m00, M.m01 - tRr.m01, M.m02 - tRr.m02, M.m10 - tRr.m10, M.m11 - tRr.m11,
-                               M.m12 - tRr.m12, M.m20 - tRr.m20, M.m21 - tRr.m21, M.m22 - tRr.m22};
-                gM = {cgr * eM.m00, cgr * eM.m01, cgr * eM.m02, cgr * eM.m10, cgr * eM.m11, cgr * eM.m12,
-                      cgr * eM.m20, cgr * eM.m21, cgr * eM.m22};
-                // dL/dR0 = -(tp gp^T + tR gM^T)  ->  contribution to dL/d(qw)
-                M3 C = mat_matT(tR, gM);
-                C.m00 = -(C.m00 + tp.x * gp.x); C.m01 = -(C.m01 + tp.x * gp.y); C.m02 = -(C.m02 + tp.x * gp.z);
-                C.m10 = -(C.m10 + tp.y * gp.x); C.m11 = -(C.m11 + tp.y * gp.y); C.m12 = -(C.m12 + tp.y * gp.z);
-                C.m20 = -(C.m20 + tp.z * gp.x); C.m21 = -(C.m21 + tp.z * gp.y); C.m22 = -(C.m22 + tp.z * gp.z);
-                const Q4 gqw_t = quat_mat_grad(qw, C);
-                *(f4*)(gpc + rank * 4) = f4{gp.x, gp.y, gp.z, 0.f};
-                *(f4*)(cqb + rank * 4) = f4{gqw_t.w, gqw_t.x, gqw_t.y, gqw_t.z};
-                const float l_p = t3.z * (e.x * e.x + e.y * e.y + e.z * e.z);
-                const float l_r = t3.w * (eM.m00 * eM.m00 + eM.m01 * eM.m01 + eM.m02 * eM.m02 + eM.m10 * eM.m10 + eM.m11 * eM.m11 +
-                                          eM.m12 * eM.m12 + eM.m20 * eM.m20 + eM.m21 * eM.m21 + eM.m22 * eM.m22);
-                *(f2*)(lpb + rank * 2) = f2{l_p, l_r}; // read by the epilogue after the last iteration
-            }
-            wave_sync();
-            STAMP(7);
-
-            // subtree sum of the tracker gradients below my child bone; on the root lane also the sum of the
-            // trackers' contributions to dL/d(qw) and (last iteration) of their loss terms
-            V3 S = {0.f, 0.f, 0.f};
-            Q4 gqw = {0.f, 0.f, 0.f, 0.f};
-            {
-                f4 g[6], c[6];
-#pragma unroll
-                for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(gpc + u * 4);
-                if (is_root) {
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(cqb + u * 4);
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
-                    if (EARLY) { // per-frame stop test of the reference's while loop (drag_pose.py:300-304,351-355)
-                        float lp = 0.f, lr = 0.f;
-                        for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(lpb + e0 * 2); lp += l.x; lr += l.y; }
-                        const f4 p0 = *(const f4*)(lds + L_LT + pf * 8);
-                        const f2 p1 = *(const f2*)(lds + L_LT + pf * 8 + 4);
-                        const float lt = (((p0.x + p0.y) + (p0.z + p0.w)) + (p1.x + p1.y)) * a.lam_tmp * (1.f / 24.f);
-                        const float tot = (lp + lr) + lt;
-                        const bool cont = (lp > a.stop_eps_pos || lr > a.stop_eps_rot) && (es_prev - tot > a.min_loss_incr) && !last;
-                        float* es = lds + L_ES + pf * 8;
-                        if (es_act) {
-                            es_prev = tot;
-                            ++es_iters;
-                            *(f4*)(es + 4) = f4{lp, lr, lt, 0.f}; // losses of this frame's last executed iteration
-                        }
-                        *(f4*)(es) = f4{es_act ? 1.f : 0.f, (es_act && !cont) ? 1.f : 0.f, (float)es_iters, (es_act && cont) ? 1.f : 0.f};
-                        es_act = es_act && cont;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const float b = (float)((sel6 >> u) & 1u);
-                    S.x += b * g[u].x; S.y += b * g[u].y; S.z += b * g[u].z;
-                }
-                if (Emax > 6) { // more than 6 trackers in a frame of this wave (uniform, rare): general path
-                    unsigned m = tmask;
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) m &= m - 1u;
-                    for (int e0 = 6; e0 < Emax; ++e0) {
-                        const f4 ge = *(const f4*)(gpc + e0 * 4);
-                        const int t = __builtin_ctz(m | 0x80000000u); // joint id of this rank (31 when exhausted)
-                        m &= m - 1u;
-                        const float b = (float)((ch_sub >> t) & 1u);
-                        S.x += b * ge.x; S.y += b * ge.y; S.z += b * ge.z;
-                        if (is_root) { const f4 ce = *(const f4*)(cqb + e0 * 4); gqw.w += ce.x; gqw.x += ce.y; gqw.y += ce.z; gqw.z += ce.w; }
-                    }
-                }
-            }
-            Q4 gq;
-            if (is_root) { // d/d(q_0) through qw = cur (x) q_0 only
-                gq = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, gqw);
-            } else { // dL/dM_j = own rotation term + S o_child^T
-                const f4 cho = *(const f4*)(icl + 256);
-                M3 X = gM;
-                X.m00 += S.x * cho.x; X.m01 += S.x * cho.y; X.m02 += S.x * cho.z;
-                X.m10 += S.y * cho.x; X.m11 += S.y * cho.y; X.m12 += S.y * cho.z;
-                X.m20 += S.z * cho.x; X.m21 += S.z * cho.y; X.m22 += S.z * cho.z;
-                gq = quat_mat_grad(q, X);
-            }
-            const float dot = q.w * gq.w + q.x * gq.x + q.y * gq.y + q.z * gq.z;
-            f4 gyv = {sd.x * (gq.w - q.w * dot) * inv, sd.y * (gq.x - q.x * dot) * inv,
-                      sd.z * (gq.y - q.y * dot) * inv, sd.w * (gq.z - q.z * dot) * inv};
-            if (is_disp) gyv = f4{sd.x * S.x, sd.y * S.y, sd.z * S.z, 0.f}; // ch_sub = every joint
-            if (dq >= 0) {
-                *(f4*)(lds + L_GY + pf * S_Y + 4 * dq) = swz4(gyv, pf >= 8);
-                if (DBG_DUMP && a.dbg && iter == 0 && fvalid) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_GY + 4 * dq) = gyv;
-            }
-        }
+        });
         if (!optimise) break; // forward-only launch (uniform)
         float WB2[26]; // bL2 weights: issued before the barrier, landed by the time it opens
         if (wave < 4) {
@@ -493,12 +313,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             if (__ballot(lds[L_ES + (lane & 15) * 8 + 3] != 0.f) == 0ull) break;
         }
     }
-#ifdef DP_PROFILE
-    if (a.dbg && tid == 0) {
-        unsigned long long* o = (unsigned long long*)a.dbg + (size_t)blockIdx.x * 20;
-        for (int i = 0; i < 20; ++i) o[i] = prof[i];
-    }
-#endif
+    prof.store(a.dbg, tid, blockIdx.x);
 
     // ================= epilogue: outputs of the LAST forward pass, rebuilt from what it left in LDS
     // (y planes, qw / d, bones, tracker loss terms, the pre-step latent) -- kept out of the hot loop
@@ -506,76 +321,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         if (zvalid) *(f4*)(lds + L_ZPRE + f16 * S_Z + zd) = swz4(*(const f4*)(zs + zd), fhi);
     }
     __syncthreads();
-    if (fvalid) {
-        const f4 y4 = *(const f4*)(yp + pf * S_Y + 4 * sq) + *(const f4*)(yp + (FPB + pf) * S_Y + 4 * sq);
-        const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
-        const Q4 r = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
-        const float inv = has_quat ? __builtin_amdgcn_rsqf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z) : 0.f;
-        const Q4 q = {r.w * inv, r.x * inv, r.y * inv, r.z * inv};
-        M3 M = quat_to_mat(q);
-        if (is_root) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-        const f4 qwv = *(const f4*)(qdb);
-        const f4 dv = *(const f4*)(qdb + 4);
-        const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
-        const M3 R0 = quat_to_mat(qw);
-        if (is_joint) {
-            if (a.pose) {
-                float* o = a.pose + (size_t)gfp * 88 + 4 * it_id;
-                o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y;
-                o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
-            }
-            if (a.pos) {
-                V3 pr = {dv.x, dv.y, dv.z};
-                for (int i = 0; i < MAX_PATH; ++i) {
-                    const unsigned k = (i < 6) ? ((plo >> (5 * i)) & 31u) : (phi & 31u);
-                    const f4 b = *(const f4*)(bone + k * 4);
-                    pr.x += b.x; pr.y += b.y; pr.z += b.z;
-                }
-                const V3 pw = mat_vec(R0, pr);
-                float* o = a.pos + ((size_t)gfp * NJ + it_id) * 3;
-                o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
-            }
-            if (a.rot) {
-                const M3 G = mat_mat(R0, M);
-                float* o = a.rot + ((size_t)gfp * NJ + it_id) * 9;
-                o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
-            }
-        }
-        if (is_root) {
-            if (a.world_rot) { float* o = a.world_rot + (size_t)gfp * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
-            if (optimise && EARLY) {
-                const float* es = lds + L_ES + pf * 8;
-                const float* zrow = lds + L_ZPRE + pf * S_Z;
-                for (int k = 0; k < LAT; k += 4)
-                    if (a.z_pre) *(f4*)(a.z_pre + (size_t)gfp * LAT + k) = *(const f4*)(zrow + k);
-                if (a.loss) { a.loss[(size_t)gfp * 3 + 0] = es[4]; a.loss[(size_t)gfp * 3 + 1] = es[5]; a.loss[(size_t)gfp * 3 + 2] = es[6]; }
-                if (a.iters) a.iters[gfp] = (int)es[2];
-            } else if (optimise) {
-                float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
-                for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(lpb + e0 * 2); lsum_p += l.x; lsum_r += l.y; }
-                const float* zrow = lds + L_ZPRE + pf * S_Z;
-                const float* ztrow = lds + L_ZT + pf * S_Z;
-                for (int k = 0; k < LAT; k += 4) {
-                    const f4 zz = *(const f4*)(zrow + k), zt = *(const f4*)(ztrow + k);
-                    if (a.z_pre) *(f4*)(a.z_pre + (size_t)gfp * LAT + k) = zz;
-                    const f4 dz = zz - zt;
-                    lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
-                }
-                if (a.loss) {
-                    a.loss[(size_t)gfp * 3 + 0] = lsum_p;
-                    a.loss[(size_t)gfp * 3 + 1] = lsum_r;
-                    a.loss[(size_t)gfp * 3 + 2] = lt * a.lam_tmp * (1.f / 24.f);
-                }
-            }
-        }
-        if (is_disp) {
-            if (a.disp) { float* o = a.disp + (size_t)gfp * 3; o[0] = r.w; o[1] = r.x; o[2] = r.y; }
-            if (a.world_disp) {
-                const V3 wd = mat_vec(R0, V3{r.w, r.x, r.y});
-                float* o = a.world_disp + (size_t)gfp * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
-            }
-        }
-    }
+    if (fvalid)
+        p3_outputs<R8>(a, id, icl, yp + pf * S_Y, fr, it_id, gfp, optimise, EARLY ? lds + L_ES + pf * 8 : nullptr,
+                       lds + L_ZPRE + pf * S_Z, lds + L_ZT + pf * S_Z);
 
     if (optimise && zvalid && blk0 + f16 < nB) { // own writes, same lane
         if (a.z) *(f4*)(a.z + (size_t)(blk0 + f16) * LAT + zd) = EARLY ? *(const f4*)(lds + L_ZFIN + f16 * S_Z + zd) : swz4(*(const f4*)(zs + zd), fhi);

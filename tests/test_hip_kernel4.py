@@ -133,7 +133,7 @@ def test_dispatch_rules(opt, dev, golden_dir):
     opt.optimize(**d, n_iter=2)
     assert opt.kernel_geometry()[:2] == (16, 512)
     opt.optimize(**d, n_iter=2, max_trackers=6)
-    assert opt.kernel_geometry()[:2] == (8, 256)  # small batch: 8-frame groups
+    assert opt.kernel_geometry()[:2] == (16, 512)  # small batch: one workgroup per CU at most, nothing to co-schedule
     opt.optimize(**d, n_iter=2, max_trackers=22)
     assert opt.kernel_geometry()[:2] == (16, 512)
     opt.optimize(**d, n_iter=5, max_trackers=6, stop_eps_pos=1e-2, stop_eps_rot=1e-2, min_loss_incr=1e-5)
@@ -155,5 +155,5 @@ def test_full_size_batches_bit_equal(opt, dev, B):
         _same(_run(opt, d, which, 256, n_iter=50, max_trackers=6), ref)
     os.environ.pop("DP_KERNEL", None)
     auto = opt.optimize(**d, n_iter=50, max_trackers=6)
-    assert opt.kernel_geometry()[:2] == ((8, 256) if B <= 4096 else (16, 256))
+    assert opt.kernel_geometry()[:2] == ((16, 512) if B <= 4096 else (16, 256))
     np.testing.assert_array_equal(auto["z"].cpu().numpy(), ref["z"])
