@@ -111,6 +111,7 @@ DEV void p3_round(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const
     const int rank = (int)((pk >> 1) & 31u);
     const float* tin = fr.trk + rank * 4;
 
+    const f4 cv = *(const f4*)(fr.qd + 20); // cur_rot of my frame: fetched with y, used by the root lane only
     const f4 y4 = *(const f4*)(y0 + 4 * id.sq) + *(const f4*)(y0 + FPB * S_Y + 4 * id.sq);
     if (DBG_DUMP && a.dbg && iter == 0 && fvalid && id.dq == id.sq) *(f4*)(a.dbg + (size_t)gfp * DBG_STRIDE + DBG_Y + 4 * id.sq) = y4;
     const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
@@ -120,7 +121,6 @@ DEV void p3_round(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const
     const Q4 q = {rq.w * inv, rq.x * inv, rq.y * inv, rq.z * inv};
     M3 M = quat_to_mat(q);
     if (id.is_root) {
-        const f4 cv = *(const f4*)(fr.qd + 20);
         const Q4 qw0 = quat_mul(Q4{cv.x, cv.y, cv.z, cv.w}, q);
         const M3 Rw = quat_to_mat(qw0); // world root rotation, computed once per frame
         *(f4*)(fr.qd) = f4{qw0.w, qw0.x, qw0.y, qw0.z};
@@ -227,7 +227,6 @@ DEV void p3_round(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const
     }
     Q4 gq;
     if (id.is_root) { // d/d(q_0) through qw = cur (x) q_0 only
-        const f4 cv = *(const f4*)(fr.qd + 20);
         gq = quat_mul(Q4{cv.x, -cv.y, -cv.z, -cv.w}, gqw);
     } else { // dL/dM_j = own rotation term + S o_child^T
         const f4 cho = *(const f4*)(icl + 256);
