@@ -31,7 +31,10 @@ struct Prof {
     }
     DEV void store(float* dbg, int tid, int block)
     {
-        if (dbg && tid == 0) {
+#ifndef DP_PROFILE_WAVE
+#define DP_PROFILE_WAVE 0 // which wave's stamps are stored (the older wave of a SIMD gets issue priority: compare 0 and 4)
+#endif
+        if (dbg && tid == 64 * DP_PROFILE_WAVE) {
             unsigned long long* o = (unsigned long long*)dbg + (size_t)block * 20;
             for (int i = 0; i < 20; ++i) o[i] = t[i];
         }
