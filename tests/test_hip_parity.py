@@ -244,6 +244,31 @@ def test_argument_validation(opt, dev, golden_dir):
         opt.optimize(**{**d, "z0": d["z0"].cpu()}, n_iter=5)
 
 
+def test_edge_sizes(opt, dev, golden_dir):
+    """empty batch and iteration-count limits are refused; the maximum iteration count and a quarter-million-frame
+    batch run, and a frame's result does not depend on where in a large batch it sits"""
+    from dragposer_amd import _lib
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    d = to_device_batch(g, dev)
+    with pytest.raises(_lib.DragPoserError) as e:
+        opt.optimize(**{k: v[:0] for k, v in d.items()}, n_iter=5)
+    assert e.value.code == _lib.DP_ERR_INVALID
+    with pytest.raises(_lib.DragPoserError):
+        opt.optimize(**d, n_iter=0)
+    o = opt.optimize(**{k: v[:16] for k, v in d.items()}, n_iter=256)  # DP_MAX_ITERS
+    assert torch.isfinite(o["z"]).all() and (o["iters"] == 256).all()
+    reps = 4096  # 64 golden frames x 4096 = 262 144 frames
+    big = {k: v.repeat((reps,) + (1,) * (v.dim() - 1)) for k, v in d.items()}
+    for hint in (0, 6):  # both kernels
+        ob = opt.optimize(**big, n_iter=3, max_trackers=hint, outputs=("z", "pos", "loss"))
+        os_ = opt.optimize(**d, n_iter=3, outputs=("z", "pos", "loss"))
+        for k in ("z", "pos", "loss"):
+            assert torch.equal(ob[k][:64], os_[k]) and torch.equal(ob[k][-64:], os_[k]), (hint, k)
+            assert torch.equal(ob[k][64 * 1777:64 * 1778], os_[k])
+
+
 def test_untracked_frame_only_feels_the_temporal_pull(opt, dev, golden_dir):
     """Edge case: a frame with no tracker at all (E_b = 0) must not produce NaN; z moves towards z_tgt."""
     from dragposer_amd.optimizer import to_device_batch
