@@ -37,6 +37,9 @@ DEV ItemId load_item(const ItemConst* ic)
     id.has_quat = kind != KIND_DISP && kind != KIND_IDLE;
     id.is_root = kind == KIND_ROOT;
     id.is_disp = kind == KIND_DISP;
+    // The root lane needs no subtree sum of position gradients (M_0 is the identity in the root frame); it uses the
+    // same accumulation slots to sum the trackers' contributions to dL/d(qw) instead, over every tracker.
+    if (id.is_root) id.ch_sub = 0xFFFFFFFFu;
     return id;
 }
 
@@ -119,16 +122,17 @@ DEV void p3_round(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const
     const float nn = rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z;
     const float inv = id.has_quat ? __builtin_amdgcn_rsqf(nn) : 0.f;
     const Q4 q = {rq.w * inv, rq.x * inv, rq.y * inv, rq.z * inv};
-    M3 M = quat_to_mat(q);
+    // one quaternion -> matrix for every lane: the root lane's is the world rotation qw = cur (x) q_0 (its own M is
+    // the identity in the root frame), every other lane's is its root-space joint rotation (1 (x) q = q exactly)
+    const Q4 qs = quat_mul(id.is_root ? Q4{cv.x, cv.y, cv.z, cv.w} : Q4{1.f, 0.f, 0.f, 0.f}, q);
+    M3 M = quat_to_mat(qs);
     if (id.is_root) {
-        const Q4 qw0 = quat_mul(Q4{cv.x, cv.y, cv.z, cv.w}, q);
-        const M3 Rw = quat_to_mat(qw0); // world root rotation, computed once per frame
-        *(f4*)(fr.qd) = f4{qw0.w, qw0.x, qw0.y, qw0.z};
-        *(f4*)(fr.qd + 8) = f4{Rw.m00, Rw.m01, Rw.m02, 0.f};
-        *(f4*)(fr.qd + 12) = f4{Rw.m10, Rw.m11, Rw.m12, 0.f};
-        *(f4*)(fr.qd + 16) = f4{Rw.m20, Rw.m21, Rw.m22, 0.f};
-        M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        *(f4*)(fr.qd) = f4{qs.w, qs.x, qs.y, qs.z};
+        *(f4*)(fr.qd + 8) = f4{M.m00, M.m01, M.m02, 0.f};
+        *(f4*)(fr.qd + 12) = f4{M.m10, M.m11, M.m12, 0.f};
+        *(f4*)(fr.qd + 16) = f4{M.m20, M.m21, M.m22, 0.f};
     }
+    if (id.is_root) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     if (id.is_disp) *(f4*)(fr.qd + 4) = f4{rq.w, rq.x, rq.y, 0.f};
     {
         const f4 cho = *(const f4*)(icl + 256); // child offset (x,y,z)
@@ -190,52 +194,45 @@ DEV void p3_round(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const
     wave_sync();
     prof.stamp(7);
 
-    // subtree sum of the tracker gradients below my child bone; on the root lane also the sum of the
-    // trackers' contributions to dL/d(qw)
-    V3 S = {0.f, 0.f, 0.f};
-    Q4 gqw = {0.f, 0.f, 0.f, 0.f};
+    // sum over the trackers selected by my item: position gradients of the trackers below my child bone (S), or, on
+    // the root lane, every tracker's contribution to dL/d(qw) -- same slots, same instructions, another table
+    f4 S4 = {0.f, 0.f, 0.f, 0.f};
     {
-        f4 g[6], c[6];
+        const float* tab = id.is_root ? fr.cq : fr.gpc;
+        f4 g[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(fr.gpc + u * 4);
-        if (id.is_root) {
-#pragma unroll
-            for (int u = 0; u < 6; ++u) c[u] = *(const f4*)(fr.cq + u * 4);
-#pragma unroll
-            for (int u = 0; u < 6; ++u) { gqw.w += c[u].x; gqw.x += c[u].y; gqw.y += c[u].z; gqw.z += c[u].w; }
-            hook();
-        }
+        for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(tab + u * 4);
+        if (id.is_root) hook();
         const unsigned sel6 = pk >> 8;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const float b = (float)((sel6 >> u) & 1u);
-            S.x += b * g[u].x; S.y += b * g[u].y; S.z += b * g[u].z;
+            S4.x += b * g[u].x; S4.y += b * g[u].y; S4.z += b * g[u].z; S4.w += b * g[u].w;
         }
         if (Emax > 6) { // more than 6 trackers in a frame of this wave (uniform, rare): general path
             unsigned m = __float_as_uint(fr.qd[24]);
 #pragma unroll
             for (int u = 0; u < 6; ++u) m &= m - 1u;
             for (int e0 = 6; e0 < Emax; ++e0) {
-                const f4 ge = *(const f4*)(fr.gpc + e0 * 4);
+                const f4 ge = *(const f4*)(tab + e0 * 4);
                 const int t = __builtin_ctz(m | 0x80000000u); // joint id of this rank (31 when exhausted)
                 m &= m - 1u;
                 const float b = (float)((id.ch_sub >> t) & 1u);
-                S.x += b * ge.x; S.y += b * ge.y; S.z += b * ge.z;
-                if (id.is_root) { const f4 ce = *(const f4*)(fr.cq + e0 * 4); gqw.w += ce.x; gqw.x += ce.y; gqw.y += ce.z; gqw.z += ce.w; }
+                S4.x += b * ge.x; S4.y += b * ge.y; S4.z += b * ge.z; S4.w += b * ge.w;
             }
         }
     }
-    Q4 gq;
-    if (id.is_root) { // d/d(q_0) through qw = cur (x) q_0 only
-        gq = quat_mul(Q4{cv.x, -cv.y, -cv.z, -cv.w}, gqw);
-    } else { // dL/dM_j = own rotation term + S o_child^T
-        const f4 cho = *(const f4*)(icl + 256);
-        M3 X = gM;
-        X.m00 += S.x * cho.x; X.m01 += S.x * cho.y; X.m02 += S.x * cho.z;
-        X.m10 += S.y * cho.x; X.m11 += S.y * cho.y; X.m12 += S.y * cho.z;
-        X.m20 += S.z * cho.x; X.m21 += S.z * cho.y; X.m22 += S.z * cho.z;
-        gq = quat_mat_grad(q, X);
-    }
+    // root: d/d(q_0) through qw = cur (x) q_0 only;  joints: dL/dM_j = own rotation term + S o_child^T.  Both forms
+    // are evaluated by every lane (straight-line code schedules better than a divergent if/else) and selected.
+    const Q4 gq_root = quat_mul(Q4{cv.x, -cv.y, -cv.z, -cv.w}, Q4{S4.x, S4.y, S4.z, S4.w});
+    const f4 cho = *(const f4*)(icl + 256);
+    M3 X = gM;
+    X.m00 += S4.x * cho.x; X.m01 += S4.x * cho.y; X.m02 += S4.x * cho.z;
+    X.m10 += S4.y * cho.x; X.m11 += S4.y * cho.y; X.m12 += S4.y * cho.z;
+    X.m20 += S4.z * cho.x; X.m21 += S4.z * cho.y; X.m22 += S4.z * cho.z;
+    const Q4 gq_joint = quat_mat_grad(q, X);
+    const Q4 gq = id.is_root ? gq_root : gq_joint;
+    const V3 S = {S4.x, S4.y, S4.z};
     const float dot = q.w * gq.w + q.x * gq.x + q.y * gq.y + q.z * gq.z;
     f4 gyv = {sd.x * (gq.w - q.w * dot) * inv, sd.y * (gq.x - q.x * dot) * inv,
               sd.z * (gq.y - q.y * dot) * inv, sd.w * (gq.z - q.z * dot) * inv};
