@@ -139,19 +139,20 @@ DEV void p3_round(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const
         const V3 u = mat_vec(M, V3{cho.x, cho.y, cho.z});
         *(f4*)(fr.bone + id.ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
     }
-    wave_sync();
-    prof.stamp(6);
-
-    const f4 qwv = *(const f4*)(fr.qd);
-    const f4 dv = *(const f4*)(fr.qd + 4);
-    const f4 r0v = *(const f4*)(fr.qd + 8), r1v = *(const f4*)(fr.qd + 12), r2v = *(const f4*)(fr.qd + 16);
-    f4 t0, t1, t2, t3; // tracker inputs of my joint (tracked lanes only)
+    // tracker inputs of my joint (loop-invariant LDS data): fetched ahead of the exchange they do not depend on
+    f4 t0, t1, t2, t3;
     if (trk) {
         t0 = *(const f4*)(tin);          // tp, cgp
         t1 = *(const f4*)(tin + 4 * R);  // tR[0..3]
         t2 = *(const f4*)(tin + 8 * R);  // tR[4..7]
         t3 = *(const f4*)(tin + 12 * R); // tR[8], cgr, clp, clr
     }
+    wave_sync();
+    prof.stamp(6);
+
+    const f4 qwv = *(const f4*)(fr.qd);
+    const f4 dv = *(const f4*)(fr.qd + 4);
+    const f4 r0v = *(const f4*)(fr.qd + 8), r1v = *(const f4*)(fr.qd + 12), r2v = *(const f4*)(fr.qd + 16);
     const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
     const M3 R0 = {r0v.x, r0v.y, r0v.z, r1v.x, r1v.y, r1v.z, r2v.x, r2v.y, r2v.z};
     V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
