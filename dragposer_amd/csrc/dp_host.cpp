@@ -394,7 +394,7 @@ static void fill_results(const dp_result* out, KArgs& k)
 // Which kernel runs a batch (all give bit-identical results):
 //   dp_kernel.hip   8 waves, 16 frames per workgroup, one workgroup per CU -- the default
 //   dp_kernel4.hip  4 waves, 16 frames per workgroup, two workgroups per CU: a few percent more throughput once every
-//                   CU has at least two workgroups (measured +5 % at 8192 frames, +10 % at 65536); needs the caller's
+//                   CU has at least two workgroups (measured +6 % at 8192 frames, +11 % at 65536); needs the caller's
 //                   max_trackers hint (<= its capacity) and a fixed iteration count.
 // DP_KERNEL=8|4x2|4x1 in the environment overrides the choice for experiments (4x1: 8-frame groups, measured slower
 // at every batch size -- the kinematics phase is bound by per-wave instruction issue, not by frames per wave).
