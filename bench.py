@@ -86,6 +86,17 @@ def cpu_baseline(batch_np, n_iter, budget_s=20.0):
     t0 = time.perf_counter()
     A.optimize(*[a[:nb] for a in args], n_iter)
     out["c_port_1core_frames_per_s"] = nb / (time.perf_counter() - t0)
+    # and the torch restatement batched over frames (what a CPU user gets by vectorising the reference), on the
+    # GPU box's CPU share
+    nt = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(nt)
+    nb = min(1024, len(args[0]))
+    R.optimize(model, *[a[:64] for a in args], 2)  # warm-up
+    t0 = time.perf_counter()
+    R.optimize(model, *[a[:nb] for a in args], n_iter)
+    out["batched_torch_frames_per_s"] = nb / (time.perf_counter() - t0)
+    out["batched_torch_threads"] = nt
+    torch.set_num_threads(1)
     out["host_cpus"] = os.cpu_count()
     return out
 
