@@ -56,6 +56,20 @@ class DpParams(C.Structure):
     ]
 
 
+class DpSeqState(C.Structure):
+    _fields_ = [
+        ("global_pos", C.c_void_p), ("global_rot", C.c_void_p), ("latent_buf", C.c_void_p), ("disp_buf", C.c_void_p),
+        ("heights_buf", C.c_void_p), ("history", C.c_int), ("n_heights", C.c_int), ("height_joints", C.c_int * 8),
+    ]
+
+
+class DpSeqStep(C.Structure):
+    _fields_ = [
+        ("adjust_joint", C.c_int), ("adjust_target_joint", C.c_int), ("adjust_weight", C.c_float),
+        ("tgt_pos", C.c_void_p), ("pose_ret", C.c_void_p), ("pos_ret", C.c_void_p),
+    ]
+
+
 class DpResult(C.Structure):
     _fields_ = [
         ("z", C.c_void_p), ("z_pre", C.c_void_p), ("pose", C.c_void_p), ("disp", C.c_void_p),
@@ -67,7 +81,7 @@ class DpResult(C.Structure):
 # every symbol include/dragposer.h declares (checked by tests/test_abi.py)
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
-    "dp_forward", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
+    "dp_forward", "dp_sequence_advance", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
 )
 
 _lib = None
@@ -100,6 +114,7 @@ def load():
     lib.dp_destroy.argtypes = [C.c_void_p]
     lib.dp_optimize.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult), C.c_void_p]
     lib.dp_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DpResult), C.c_void_p]
+    lib.dp_sequence_advance.argtypes = [C.c_void_p, C.c_int, C.POINTER(DpResult), C.POINTER(DpSeqState), C.POINTER(DpSeqStep), C.c_void_p]
     lib.dp_kernel_geometry.argtypes = [C.c_void_p, _i, _i, _i]
     # private test hooks (not part of include/dragposer.h)
     lib.dp_optimize_debug.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult),

@@ -11,6 +11,7 @@
 
 #include "../../include/dragposer.h"
 #include "dp_kernel.h"
+#include "dp_sequence.h"
 
 using namespace dpl;
 
@@ -23,6 +24,7 @@ struct dp_ctx {
     dp_folded folded;
     std::vector<unsigned> smask;
     std::string err;
+    float mean_q0[4] = {0, 0, 0, 0}, std_q0[4] = {1, 1, 1, 1}; // root quaternion channels (sequence epilogue)
     int last_kernel = 0; // 8, 41 (4 waves x 8 frames) or 42 (4 waves x 16 frames): what the last launch used
 };
 
@@ -292,6 +294,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     dp_ctx* ctx = new dp_ctx();
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int k = 0; k < 4; ++k) { ctx->mean_q0[k] = model->mean_q[k]; ctx->std_q0[k] = model->std_q[k]; }
     int rc = dp_fold_decoder(model, &ctx->folded);
     std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
     ctx->smask.assign(NWAVE * NGEMM, 0u);
@@ -471,4 +474,36 @@ extern "C" int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float
     k.z = nullptr; k.z_pre = nullptr; k.loss = nullptr; k.iters = nullptr;
     k.n_frames = n_frames; k.n_iter = 1; k.mode = 1;
     return launch(ctx, k, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-frame epilogue of S sequences (reference drag_pose.py:369-402), see include/dragposer.h
+extern "C" int dp_sequence_advance(dp_ctx* ctx, int n_seq, const dp_result* res, const dp_seq_state* st, const dp_seq_step* step, void* stream)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    if (n_seq <= 0 || !res || !st || !step) return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: bad arguments");
+    if (!res->z_pre || !res->pose || !res->disp || !res->world_disp || !res->world_rot || !res->pos)
+        return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: the frame result needs z_pre, pose, disp, world_disp, world_rot and pos");
+    if (!st->global_pos || !st->global_rot || !st->latent_buf || !st->disp_buf || !st->heights_buf)
+        return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: NULL state array");
+    if (st->history < 1 || st->n_heights < 0 || st->n_heights > DP_MAX_HEIGHT_JOINTS)
+        return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: history / n_heights out of range");
+    for (int h = 0; h < st->n_heights; ++h)
+        if (st->height_joints[h] < 0 || st->height_joints[h] >= NJ) return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: bad height joint");
+    if (step->adjust_joint >= NJ || (step->adjust_joint >= 0 && (step->adjust_target_joint < 0 || step->adjust_target_joint >= NJ || !step->tgt_pos)))
+        return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: bad joint adjustment");
+    SeqArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_seq = n_seq; a.history = st->history; a.n_heights = st->n_heights;
+    for (int h = 0; h < st->n_heights; ++h) a.height_joints[h] = st->height_joints[h];
+    a.adjust_joint = step->adjust_joint < 0 ? -1 : step->adjust_joint;
+    a.adjust_target_joint = step->adjust_target_joint; a.adjust_weight = step->adjust_weight;
+    for (int k = 0; k < 4; ++k) { a.mean_q0[k] = ctx->mean_q0[k]; a.std_q0[k] = ctx->std_q0[k]; }
+    a.z_pre = res->z_pre; a.pose = res->pose; a.disp = res->disp; a.world_disp = res->world_disp; a.world_rot = res->world_rot; a.pos = res->pos;
+    a.tgt_pos = step->tgt_pos;
+    a.global_pos = st->global_pos; a.global_rot = st->global_rot; a.latent_buf = st->latent_buf; a.disp_buf = st->disp_buf;
+    a.heights_buf = st->heights_buf; a.pose_ret = step->pose_ret; a.pos_ret = step->pos_ret;
+    hipError_t e = dp_launch_sequence_advance(&a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("sequence kernel launch: ") + hipGetErrorString(e));
+    return DP_OK;
 }

@@ -1,0 +1,19 @@
+// dp_sequence.h -- argument block of the sequence-advance kernel (dp_sequence.hip), filled by dp_host.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct SeqArgs {
+    int n_seq, history, n_heights;
+    int height_joints[8];
+    int adjust_joint, adjust_target_joint;
+    float adjust_weight;
+    float mean_q0[4], std_q0[4]; // de-normalisation of the root quaternion channels
+    // frame results (dp_result of this frame)
+    const float *z_pre, *pose, *disp, *world_disp, *world_rot, *pos;
+    const float* tgt_pos;
+    // state
+    float *global_pos, *global_rot, *latent_buf, *disp_buf, *heights_buf;
+    float *pose_ret, *pos_ret;
+};
+
+extern "C" hipError_t dp_launch_sequence_advance(const SeqArgs* args, hipStream_t stream);

@@ -5,14 +5,16 @@ What stays here (PyTorch-ROCm device tensors, a handful of tiny ops per frame):
   * the state the reference keeps between frames: latent, current global position /
     rotation, the 60-deep latent / displacement / height ring buffers, the temporal target buffer;
   * the temporal target block (row a12, drag_pose.py:234-294), which calls the Transformer;
-  * the per-frame epilogue (row a11, drag_pose.py:369-402): global pose update, joint adjustment,
-    buffer shifts, root channels of the returned pose.
+  * nothing of the per-frame epilogue (row a11, drag_pose.py:369-402: global pose update, joint adjustment,
+    buffer shifts, root channels of the returned pose): that is `dp_sequence_advance`, one launch on the state
+    tensors held here.
 What does not: decode / FK / loss / backward / Adam / the while-condition -- those run inside
 `LatentOptimizer.optimize` (one kernel launch per frame index for all S sequences).
 
 `run()` keeps the reference's argument names and meaning; tensors carry a leading sequence
 dimension S (a single sequence may omit it, then the results omit it too, like the reference).
 """
+import numpy as np
 import torch
 
 from .model import NJ
@@ -38,6 +40,10 @@ class DragPose:
         self.latent = None
         self.last = None
         self._idx_cache = {}
+        self._trk_cache = {}
+        self._out = [None, None]
+        self._flip = 0
+        self._offsets_checked = False
 
     def _index(self, values):
         """device index tensor for a Python list, created once (no host->device copy inside a captured step)"""
@@ -89,40 +95,58 @@ class DragPose:
             self.target_latent_buffer = buf
 
     # ------------------------------------------------------------------ one frame (drag_pose.py:196-414)
+    def _trackers(self, mask_joints, weights_joints):
+        """device copies of the tracker list and the dense per-joint weight / flag arrays of the C ABI, built once per
+        distinct (mask_joints, weights_joints) -- they are the same objects frame after frame"""
+        mj_h = np.asarray(mask_joints.cpu() if isinstance(mask_joints, torch.Tensor) else mask_joints, dtype=np.int64).reshape(-1)
+        wj_h = np.asarray(weights_joints.cpu() if isinstance(weights_joints, torch.Tensor) else weights_joints, dtype=np.float32).reshape(-1, 2)
+        key = (mj_h.tobytes(), wj_h.tobytes())
+        if key not in self._trk_cache:
+            dev, S = self.device, self.S
+            if wj_h.shape[0] != mj_h.shape[0]:
+                raise ValueError("target_ee_pos / target_ee_rot / weights_joints must have one row per entry of mask_joints")
+            mj = torch.from_numpy(mj_h).to(dev)
+            w = torch.zeros(S, NJ, 2, device=dev)
+            tracked = torch.zeros(S, NJ, dtype=torch.uint8, device=dev)
+            w.index_copy_(1, mj, torch.from_numpy(wj_h).to(dev).unsqueeze(0).expand(S, -1, -1).contiguous())
+            tracked.index_fill_(1, mj, 1)
+            # targets of untracked joints are never read, so the dense target arrays are allocated once and only the
+            # tracked rows are rewritten every frame
+            self._trk_cache[key] = dict(mj=mj, mj_host=mj_h, w=w, tracked=tracked, tgt_pos=torch.zeros(S, NJ, 3, device=dev),
+                                        tgt_rot=torch.zeros(S, NJ, 9, device=dev))
+        return self._trk_cache[key]
+
     def run(self, target_ee_pos, target_ee_rot, mask_joints, weights_joints, offsets=None, stop_eps_pos=1e-2,
             stop_eps_rot=1e-2, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-3, lambda_rot=1, lambda_temporal=1,
             temporal_future_window=60, height_indices=(0, 4, 8, 13, 17, 21), joint_adjustment_indices=None,
-            joint_adjustment_weight=0.01, verbose=False):
+            joint_adjustment_weight=0.01, verbose=False, out_pose=None, out_pos=None):
+        """One frame for every sequence: two kernel launches (optimise loop, epilogue) plus two row scatters of the
+        targets.  `out_pose` [S,88] / `out_pos` [S,3]: optional caller storage for the returned tensors."""
         dev, S = self.device, self.S
         squeeze = torch.as_tensor(target_ee_pos).dim() == 2
         tp = torch.as_tensor(target_ee_pos, dtype=torch.float32, device=dev).reshape(S, -1, 3)
         tR = torch.as_tensor(target_ee_rot, dtype=torch.float32, device=dev).reshape(S, -1, 9)
-        mj = torch.as_tensor(mask_joints, dtype=torch.int64, device=dev).reshape(-1)
-        wj = torch.as_tensor(weights_joints, dtype=torch.float32, device=dev).reshape(-1, 2)
-        E = mj.numel()
-        if tp.shape[1] != E or tR.shape[1] != E or wj.shape[0] != E:
+        trk = self._trackers(mask_joints, weights_joints)
+        E = trk["mj"].numel()
+        if tp.shape[1] != E or tR.shape[1] != E:
             raise ValueError("target_ee_pos / target_ee_rot / weights_joints must have one row per entry of mask_joints")
-        if offsets is not None and not torch.allclose(torch.as_tensor(offsets, dtype=torch.float32, device=dev).reshape(NJ, 3),
-                                                      self.offsets, atol=1e-6):
-            raise ValueError("offsets differ from the skeleton the optimiser context was created with")
+        if offsets is not None and not self._offsets_checked:
+            if not torch.allclose(torch.as_tensor(offsets, dtype=torch.float32, device=dev).reshape(NJ, 3), self.offsets, atol=1e-6):
+                raise ValueError("offsets differ from the skeleton the optimiser context was created with")
+            self._offsets_checked = True  # (a device->host round trip: once, not per frame)
 
         self._temporal_targets(temporal_future_window)
         target_latent = self.target_latent_buffer[:, self.current_index].contiguous()
+        trk["tgt_pos"].index_copy_(1, trk["mj"], tp)
+        trk["tgt_rot"].index_copy_(1, trk["mj"], tR)
 
-        # scatter the E tracker rows to dense per-joint arrays (the C ABI's layout)
-        tgt_pos = torch.zeros(S, NJ, 3, device=dev)
-        tgt_rot = torch.zeros(S, NJ, 9, device=dev)
-        w = torch.zeros(S, NJ, 2, device=dev)
-        tracked = torch.zeros(S, NJ, dtype=torch.uint8, device=dev)
-        tgt_pos.index_copy_(1, mj, tp)
-        tgt_rot.index_copy_(1, mj, tR)
-        w.index_copy_(1, mj, wj.unsqueeze(0).expand(S, -1, -1).contiguous())
-        tracked.index_fill_(1, mj, 1)
-
-        out = self.opt.optimize(self.latent.contiguous(), target_latent, self.current_global_rot.contiguous(), tgt_pos, tgt_rot,
-                                w, tracked, n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot),
+        self._flip ^= 1  # two result sets, alternated: `last` (and the latent it carries) stays valid while the next frame runs
+        if self._out[self._flip] is None:
+            self._out[self._flip] = self.opt.allocate_outputs(S)
+        out = self.opt.optimize(self.latent, target_latent, self.current_global_rot, trk["tgt_pos"], trk["tgt_rot"], trk["w"],
+                                trk["tracked"], n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot),
                                 lambda_tmp=float(lambda_temporal), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
-                                min_loss_incr=min_loss_incr, max_trackers=E)
+                                min_loss_incr=min_loss_incr, max_trackers=E, out=self._out[self._flip])
         self.last = out
         self.latent = out["z"]
         if verbose:
@@ -130,22 +154,17 @@ class DragPose:
             print(f"Loss sqrt(Pos): {l[:, 0].sqrt().mean():.5f} // Loss Rot: {l[:, 1].mean():.5f} // "
                   f"Loss Temporal: {l[:, 2].mean():.5f} // Iter: {it.float().mean():.1f}")
 
-        # ---- epilogue (drag_pose.py:369-402)
-        self.current_global_pos = self.current_global_pos + out["world_disp"]
-        self.current_global_rot = out["world_rot"]
-        displacement = out["disp"].clone()
+        # ---- epilogue (drag_pose.py:369-402): one launch, state updated in place
+        adjust = None
         if joint_adjustment_indices is not None:
             joint_index, ee_index = joint_adjustment_indices
-            adj = (tp[:, ee_index] - out["pos"][:, joint_index]) * joint_adjustment_weight
-            self.current_global_pos = self.current_global_pos + adj
-            displacement = displacement + adj
-        self.latent_buffer = torch.cat((self.latent_buffer[:, 1:], out["z_pre"].unsqueeze(1)), dim=1)
-        self.displacement_buffer = torch.cat((self.displacement_buffer[:, 1:], displacement.unsqueeze(1)), dim=1)
-        heights = (out["pos"] + self.current_global_pos.unsqueeze(1)).index_select(1, self._index(height_indices))[:, :, 1]
-        self.heights_buffer = torch.cat((self.heights_buffer[:, 1:], heights.unsqueeze(1)), dim=1)
-        pose = out["pose"].clone()
-        pose[:, :4] = (self.current_global_rot - self.means_q[:4]) / self.stds_q[:4]
+            adjust = (int(joint_index), int(trk["mj_host"][ee_index]), float(joint_adjustment_weight))
+        pose = out_pose if out_pose is not None else torch.empty(S, 88, device=dev)
+        gpos = out_pos if out_pos is not None else torch.empty(S, 3, device=dev)
+        self.opt.sequence_advance(out, self.current_global_pos, self.current_global_rot, self.latent_buffer, self.displacement_buffer,
+                                  self.heights_buffer, tuple(int(h) for h in height_indices), pose_ret=pose, pos_ret=gpos,
+                                  adjust=adjust, tgt_pos=trk["tgt_pos"])
         self.current_index = 0 if temporal_future_window == 0 else (self.current_index + 1) % temporal_future_window
         if squeeze and S == 1:
-            return pose[0], self.current_global_pos[0]
-        return pose, self.current_global_pos
+            return pose[0], gpos[0]
+        return pose, gpos

@@ -104,8 +104,9 @@ def evaluate_file(args, input_path, opt, encoder, temporal_pack, cfg, raw):
         pose, pos = drag.run(tp, tR[i:i + 1], mask_idx, weights, stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=args.max_iter,
                              min_loss_incr=0.00001, learning_rate=1e-2, lambda_rot=1, lambda_temporal=lam_tmp,
                              temporal_future_window=window, height_indices=HEIGHT_INDICES, joint_adjustment_indices=ja,
-                             joint_adjustment_weight=cfg["joint_adjustment_weight"], verbose=args.verbose)
-        poses[i], out_pos[i], iters[i] = pose[0], pos[0], drag.last["iters"][0]
+                             joint_adjustment_weight=cfg["joint_adjustment_weight"], verbose=args.verbose,
+                             out_pose=poses[i:i + 1], out_pos=out_pos[i:i + 1])
+        iters[i:i + 1] = drag.last["iters"]
     torch.cuda.synchronize()
     elapsed = time.time() - t0
     name = os.path.basename(input_path)

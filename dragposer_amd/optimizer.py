@@ -80,6 +80,10 @@ class LatentOptimizer:
     def _fail(self, rc):
         raise _lib.DragPoserError(rc, _lib.last_error(self.ctx))
 
+    def allocate_outputs(self, B, names=None):
+        """a reusable set of result tensors for `optimize(..., out=...)`"""
+        return {n: torch.empty((B,) + _OUT_SPECS[n][0], dtype=_OUT_SPECS[n][1], device=self.device) for n in (names or _OUT_SPECS)}
+
     def _outputs(self, B, names, out):
         res = _lib.DpResult()
         tensors = {}
@@ -139,6 +143,43 @@ class LatentOptimizer:
         if rc != _lib.DP_OK:
             self._fail(rc)
         return tensors
+
+
+    def sequence_advance(self, frame, global_pos, global_rot, latent_buf, disp_buf, heights_buf, height_joints, pose_ret=None,
+                         pos_ret=None, adjust=None, tgt_pos=None):
+        """The reference's per-frame epilogue (drag_pose.py:369-402) for S sequences in one launch: updates
+        `global_pos`, `global_rot` and the three history buffers IN PLACE from `frame` (the dict `optimize` returned:
+        z_pre, pose, disp, world_disp, world_rot, pos) and fills `pose_ret` / `pos_ret`.
+        `adjust` = (joint, target_joint, weight) or None; `tgt_pos` = this frame's dense [S,22,3] targets."""
+        S = int(global_pos.shape[0])
+        dev = self.device
+        res = _lib.DpResult()
+        for name in ("z_pre", "pose", "disp", "world_disp", "world_rot", "pos"):
+            shape, dtype = _OUT_SPECS[name]
+            setattr(res, name, _check(frame[name], name, (S,) + shape, dtype, dev))
+        H, NH = int(latent_buf.shape[1]), len(height_joints)
+        st = _lib.DpSeqState()
+        st.global_pos = _check(global_pos, "global_pos", (S, 3), torch.float32, dev)
+        st.global_rot = _check(global_rot, "global_rot", (S, 4), torch.float32, dev)
+        st.latent_buf = _check(latent_buf, "latent_buf", (S, H, LATENT), torch.float32, dev)
+        st.disp_buf = _check(disp_buf, "disp_buf", (S, H, 3), torch.float32, dev)
+        st.heights_buf = _check(heights_buf, "heights_buf", (S, H, NH), torch.float32, dev)
+        st.history, st.n_heights = H, NH
+        for i, j in enumerate(height_joints):
+            st.height_joints[i] = int(j)
+        step = _lib.DpSeqStep()
+        step.adjust_joint = -1
+        if adjust is not None:
+            step.adjust_joint, step.adjust_target_joint, step.adjust_weight = int(adjust[0]), int(adjust[1]), float(adjust[2])
+            step.tgt_pos = _check(tgt_pos, "tgt_pos", (S, NJ, 3), torch.float32, dev)
+        if pose_ret is not None:
+            step.pose_ret = _check(pose_ret, "pose_ret", (S, 88), torch.float32, dev)
+        if pos_ret is not None:
+            step.pos_ret = _check(pos_ret, "pos_ret", (S, 3), torch.float32, dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self.lib.dp_sequence_advance(self.ctx, S, C.byref(res), C.byref(st), C.byref(step), stream)
+        if rc != _lib.DP_OK:
+            self._fail(rc)
 
 
 def to_device_batch(np_batch, device):

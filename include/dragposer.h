@@ -11,6 +11,8 @@
  *                            and optim.Adam.step() (drag_pose.py:218,342-344) -- for B frames at once
  *   dp_forward               Decoder.forward + the FK part of DragPose.loss (drag_pose.py:84-113) with
  *                            no loss/backward: pose, world root transform and joint positions of z
+ *   dp_sequence_advance      the per-frame epilogue of DragPose.run (drag_pose.py:369-402): global pose update,
+ *                            joint adjustment, history buffers -- for S sequences in lock-step
  *   dp_fold_decoder          host-only helper: the algebra the reference re-does every call
  *                            (W*mask, skeleton.py:120; unpool matmul, skeleton.py:245) done once
  *
@@ -135,6 +137,37 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* params, const 
 
 /* decode + FK only; `out` fields z, z_pre, loss, iters are ignored. */
 int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float* cur_rot, const dp_result* out, void* hip_stream);
+
+/* ---- per-frame epilogue of a sequence (reference: DragPose.run, drag_pose.py:369-402,414) -------------------------
+ * After dp_optimize has solved frame t of S sequences advancing in lock-step (one row of every array per sequence),
+ * dp_sequence_advance applies what the reference does between the optimise loop and `return`: global position /
+ * rotation update, optional joint adjustment, the three history buffers shifted by one frame with the new entry
+ * appended (the state of drag_pose.py:47-64), and the returned pose with its root channels replaced by the
+ * normalised global rotation.  One launch, asynchronous on the stream, no host synchronisation. */
+#define DP_MAX_HEIGHT_JOINTS 8
+typedef struct dp_seq_state {   /* DEVICE pointers; S sequences */
+    float* global_pos;  /* [S][3]      current_global_pos (in/out) */
+    float* global_rot;  /* [S][4]      current_global_rot (out: world_rot of this frame) */
+    float* latent_buf;  /* [S][H][24]  latent_buffer       (in/out, newest entry last) */
+    float* disp_buf;    /* [S][H][3]   displacement_buffer (in/out) */
+    float* heights_buf; /* [S][H][NH]  heights_buffer      (in/out) */
+    int history;        /* H (the reference keeps 60 frames) */
+    int n_heights;      /* NH <= DP_MAX_HEIGHT_JOINTS */
+    int height_joints[DP_MAX_HEIGHT_JOINTS]; /* height_indices (drag_pose.py:393) */
+} dp_seq_state;
+
+typedef struct dp_seq_step {
+    int adjust_joint;        /* joint_adjustment_indices[0], or -1: no joint adjustment (drag_pose.py:377-384) */
+    int adjust_target_joint; /* the joint whose tracker row joint_adjustment_indices[1] selects (mask_joints[ee_index]) */
+    float adjust_weight;     /* joint_adjustment_weight */
+    const float* tgt_pos;    /* [S][22][3] this frame's dense targets (read for the adjustment only; may be NULL when off) */
+    float* pose_ret;         /* [S][88] returned pose (drag_pose.py:399-402,414); may be NULL */
+    float* pos_ret;          /* [S][3]  returned global position; may be NULL */
+} dp_seq_step;
+
+/* `res` = the dp_result dp_optimize filled for this frame: z_pre, pose, disp, world_disp, world_rot, pos are read. */
+int dp_sequence_advance(dp_ctx* ctx, int n_sequences, const dp_result* res, const dp_seq_state* state, const dp_seq_step* step,
+                        void* hip_stream);
 
 /* Device-buffer helpers for callers that have no HIP binding of their own (the native Unity drop-in,
  * include/dragposer_unity.h).  Thin wrappers over hipMalloc / hipFree / hipMemcpyAsync / hipStreamSynchronize on the

@@ -87,6 +87,45 @@ def test_teacher_forced_frames_match_the_reference(golden_dir, name):
     np.testing.assert_allclose(o["pose"][:, 4:], g["pose_ret"].reshape(B, 88)[:, 4:], atol=1e-4, rtol=0)
 
 
+def test_sequence_advance_matches_the_reference_epilogue():
+    """dp_sequence_advance against drag_pose.py:369-402 restated with torch ops, on random state: S = 5 sequences,
+    with and without joint adjustment; exact equality (the same fp32 operations in the same order)."""
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    dev = torch.device("cuda:0")
+    opt = LatentOptimizer(device=dev)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    S, H = 5, 60
+    r = lambda *shape: torch.randn(*shape, generator=g).to(dev)
+    hj = (0, 4, 8, 13, 17, 21)
+    means_q = torch.from_numpy(opt.host_model.arrays["mean_q"]).to(dev)
+    stds_q = torch.from_numpy(opt.host_model.arrays["std_q"]).to(dev)
+    for adjust in (None, (13, 17, 0.01)):
+        frame = dict(z_pre=r(S, 24), pose=r(S, 88), disp=r(S, 3), world_disp=r(S, 3), world_rot=r(S, 4), pos=r(S, 22, 3))
+        tgt = r(S, 22, 3)
+        gp, gr, lb, db, hb = r(S, 3), r(S, 4), r(S, H, 24), r(S, H, 3), r(S, H, 6)
+        # reference epilogue
+        e_gp = gp + frame["world_disp"]
+        e_disp = frame["disp"].clone()
+        if adjust is not None:
+            adj = (tgt[:, adjust[1]] - frame["pos"][:, adjust[0]]) * adjust[2]
+            e_gp = e_gp + adj
+            e_disp = e_disp + adj
+        e_lb = torch.cat((lb[:, 1:], frame["z_pre"].unsqueeze(1)), dim=1)
+        e_db = torch.cat((db[:, 1:], e_disp.unsqueeze(1)), dim=1)
+        heights = (frame["pos"] + e_gp.unsqueeze(1))[:, list(hj), 1]
+        e_hb = torch.cat((hb[:, 1:], heights.unsqueeze(1)), dim=1)
+        e_pose = frame["pose"].clone()
+        e_pose[:, :4] = (frame["world_rot"] - means_q[:4]) / stds_q[:4]
+        pose_ret, pos_ret = torch.empty(S, 88, device=dev), torch.empty(S, 3, device=dev)
+        opt.sequence_advance(frame, gp, gr, lb, db, hb, hj, pose_ret=pose_ret, pos_ret=pos_ret, adjust=adjust, tgt_pos=tgt)
+        torch.cuda.synchronize()
+        for got, exp in ((gp, e_gp), (gr, frame["world_rot"]), (lb, e_lb), (db, e_db), (hb, e_hb), (pose_ret, e_pose), (pos_ret, e_gp)):
+            assert torch.equal(got, exp)
+    with pytest.raises(Exception):
+        opt.sequence_advance(frame, gp, gr, lb, db, hb, (0, 99), pose_ret=pose_ret)  # joint index out of range
+
+
 def test_single_sequence_keeps_reference_shapes():
     from dragposer_amd.drag_pose import DragPose
     from dragposer_amd.optimizer import LatentOptimizer
