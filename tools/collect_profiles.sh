@@ -24,6 +24,6 @@ for fr in 1024 2048 4096 8192 16384 65536; do
 done > $O/batch_sweep.txt
 echo "sweep done"
 # 4. phase stamps (diagnostic build)
-( PWAVE=0 SPECS="4096:0:8 1024:6:4x1 4096:6:4x1 4096:6:4x2 8192:6:4x2" bash tools/k4prof.sh; echo "---- stamps of wave 4 (second-dispatched half)"; PWAVE=4 SPECS="4096:0:8" bash tools/k4prof.sh ) > $O/phase_cycles_variants.txt 2>&1
+( PWAVE=0 SPECS="4096:0:8 1024:6:4x1 4096:6:4x1 4096:6:4x2 8192:6:4x2" bash tools/phase_profile.sh; echo "---- stamps of wave 4 (second-dispatched half)"; PWAVE=4 SPECS="4096:0:8" bash tools/phase_profile.sh ) > $O/phase_cycles_variants.txt 2>&1
 echo "phases done"
 ls $O
