@@ -62,7 +62,9 @@ def result_to_bvh(poses, global_pos, means, stds, bvh, out_path):
     bvh.save(out_path)
 
 
-def evaluate_file(args, input_path, opt, encoder, temporal_pack, cfg, raw):
+def prepare_file(args, input_path, opt, encoder, cfg, raw):
+    """BVH -> everything one sequence needs on the device (eval_drag.py:133-202): normalised motion, per-frame
+    targets relative to the root, the ground-truth root trajectory, the encoder's initial latent."""
     dev = opt.device
     means = {"dqs": raw["means.dqs"], "displacement": raw["means.displacement"]}
     stds = {"dqs": raw["stds.dqs"], "displacement": raw["stds.displacement"]}
@@ -72,54 +74,90 @@ def evaluate_file(args, input_path, opt, encoder, temporal_pack, cfg, raw):
         raise SystemExit(f"{input_path}: skeleton differs from the one the model fixture was exported with")
     n_frames = len(m["dqs"]) if args.max_frames is None else min(args.max_frames, len(m["dqs"]))
     mask_idx = np.nonzero(np.asarray(cfg["mask"]))[0]
-    weights = np.asarray(cfg["weights"], np.float32)[mask_idx]
-    temporal, means_latent, stds_latent = temporal_pack
-    lam_tmp = cfg["lambda_temporal"] if temporal is not None else 0.0
-    window = cfg["temporal_future_window"] if temporal is not None else 0
-
     # targets (eval_drag.py:164-202): FK of the ground-truth pose with the root at the origin, per frame; the
     # root translation relative to the running estimate is added inside the loop, on the device
     rq = m["root_quats"].copy()
     rq[:, 0] = m["global_rot"]
     local = Q.from_root_space(rq, m["parents"])
     p_rel, g_rot = Q.fk(local[:n_frames], np.zeros((n_frames, 3)), m["offsets"].astype(np.float64), m["parents"])
-    tp_rel = torch.tensor(p_rel[:, mask_idx], dtype=torch.float32, device=dev)
-    tR = torch.tensor(Q.to_matrix(g_rot[:, mask_idx]).reshape(n_frames, len(mask_idx), 9), dtype=torch.float32, device=dev)
-    gpos = torch.tensor(m["global_pos"], device=dev)
-
-    drag = DragPose(opt, temporal, means_latent, stds_latent, n_sequences=1)
     gen = torch.Generator(device="cpu").manual_seed(2222)  # train.param["seed"]
     z0 = encoder.sample(torch.tensor(m["dqs"][0:1], device=dev), generator=gen)  # drag_pose.py:50
-    drag.set_initial_state(z0, m["global_pos"][0], m["global_rot"][0], m["heights"][0])
+    return dict(path=input_path, bvh=bvh, m=m, n_frames=n_frames, means=means, stds=stds, z0=z0,
+                tp_rel=torch.tensor(p_rel[:, mask_idx], dtype=torch.float32, device=dev),
+                tR=torch.tensor(Q.to_matrix(g_rot[:, mask_idx]).reshape(n_frames, len(mask_idx), 9), dtype=torch.float32, device=dev),
+                gpos=torch.tensor(m["global_pos"][:n_frames], dtype=torch.float32, device=dev))
+
+
+def run_sequences(args, seqs, opt, temporal_pack, cfg):
+    """The frame loop (eval_drag.py:181-227) for S prepared sequences advancing in lock-step: one `DragPose.run`
+    (two kernel launches) per frame index whatever S.  Sequences shorter than the longest keep receiving their last
+    frame's targets; their surplus frames are dropped."""
+    dev, S = opt.device, len(seqs)
+    T = max(q["n_frames"] for q in seqs)
+    mask_idx = np.nonzero(np.asarray(cfg["mask"]))[0]
+    weights = np.asarray(cfg["weights"], np.float32)[mask_idx]
+    temporal, means_latent, stds_latent = temporal_pack
+    lam_tmp = cfg["lambda_temporal"] if temporal is not None else 0.0
+    window = cfg["temporal_future_window"] if temporal is not None else 0
+    pad = lambda t: torch.cat((t, t[-1:].expand(T - t.shape[0], *t.shape[1:])), dim=0) if t.shape[0] < T else t
+    tp_rel = torch.stack([pad(q["tp_rel"]) for q in seqs], dim=1).contiguous()  # [T, S, E, 3]
+    tR = torch.stack([pad(q["tR"]) for q in seqs], dim=1).contiguous()
+    gpos = torch.stack([pad(q["gpos"]) for q in seqs], dim=1).contiguous()      # [T, S, 3]
+
+    drag = DragPose(opt, temporal, means_latent, stds_latent, n_sequences=S)
+    drag.set_initial_state(torch.cat([q["z0"] for q in seqs], dim=0), np.stack([q["m"]["global_pos"][0] for q in seqs]),
+                           np.stack([q["m"]["global_rot"][0] for q in seqs]), np.stack([q["m"]["heights"][0] for q in seqs]))
     ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
-    poses = torch.zeros(n_frames, 88, device=dev)
-    out_pos = torch.zeros(n_frames, 3, device=dev)
-    iters = torch.zeros(n_frames, dtype=torch.int32, device=dev)
+    poses = torch.zeros(T, S, 88, device=dev)
+    out_pos = torch.zeros(T, S, 3, device=dev)
+    iters = torch.zeros(T, S, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     t0 = time.time()
-    for i in range(n_frames):
+    for i in range(T):
         if i % 1000 == 0:
-            print(f"Frame: {i + 1} out of {n_frames}", flush=True)
-        tp = tp_rel[i:i + 1] + (gpos[i] - drag.current_global_pos).unsqueeze(1)  # eval_drag.py:186-199
-        pose, pos = drag.run(tp, tR[i:i + 1], mask_idx, weights, stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=args.max_iter,
-                             min_loss_incr=0.00001, learning_rate=1e-2, lambda_rot=1, lambda_temporal=lam_tmp,
-                             temporal_future_window=window, height_indices=HEIGHT_INDICES, joint_adjustment_indices=ja,
-                             joint_adjustment_weight=cfg["joint_adjustment_weight"], verbose=args.verbose,
-                             out_pose=poses[i:i + 1], out_pos=out_pos[i:i + 1])
-        iters[i:i + 1] = drag.last["iters"]
+            print(f"Frame: {i + 1} out of {T}", flush=True)
+        tp = tp_rel[i] + (gpos[i] - drag.current_global_pos).unsqueeze(1)  # eval_drag.py:186-199
+        drag.run(tp, tR[i], mask_idx, weights, stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=args.max_iter,
+                 min_loss_incr=0.00001, learning_rate=1e-2, lambda_rot=1, lambda_temporal=lam_tmp,
+                 temporal_future_window=window, height_indices=HEIGHT_INDICES, joint_adjustment_indices=ja,
+                 joint_adjustment_weight=cfg["joint_adjustment_weight"], verbose=args.verbose, out_pose=poses[i], out_pos=out_pos[i])
+        iters[i] = drag.last["iters"]
     torch.cuda.synchronize()
     elapsed = time.time() - t0
-    name = os.path.basename(input_path)
+    poses, out_pos, iters = poses.cpu().numpy(), out_pos.cpu().numpy(), iters.cpu().numpy()
+    return [dict(poses=poses[:q["n_frames"], k], pos=out_pos[:q["n_frames"], k], iters=iters[:q["n_frames"], k]) for k, q in enumerate(seqs)], elapsed, lam_tmp, temporal is not None
+
+
+def finish_file(args, q, res, elapsed, lam_tmp, has_temporal, shared=1):
+    """write the result BVH, report the reference's metrics (eval_drag.py:229-252)"""
+    name = os.path.basename(q["path"])
     out_path = os.path.join(args.out_dir, "eval_" + name)
-    result_to_bvh(poses.cpu().numpy(), out_pos.cpu().numpy(), means, stds, bvh, out_path)
-    mpjpe, mpeepe = eval_pos_error(BVH().load(input_path), BVH().load(out_path))
+    result_to_bvh(res["poses"], res["pos"], q["means"], q["stds"], q["bvh"], out_path)
+    mpjpe, mpeepe = eval_pos_error(BVH().load(q["path"]), BVH().load(out_path))
+    n = q["n_frames"]
     print(f"Evaluate Loss: {mpjpe + mpeepe}")
     print(f"Mean Per Joint Position Error: {mpjpe}")
     print(f"Mean End Effector Position Error: {mpeepe}")
-    print(f"Time: {elapsed}")
-    print(f"Frames: {n_frames}  ({n_frames / elapsed:.1f} frames/s, mean iterations/frame {iters.float().mean().item():.1f}, "
-          f"lambda_temporal {lam_tmp}{'' if temporal is not None else ' -- no temporal checkpoint given: pull term off'})")
-    return dict(mpjpe=mpjpe, mpeepe=mpeepe, time=elapsed, frames=n_frames, out=out_path, mean_iters=iters.float().mean().item())
+    print(f"Time: {elapsed}" + (f"  (shared by {shared} sequences in lock-step)" if shared > 1 else ""))
+    print(f"Frames: {n}  ({n / elapsed:.1f} frames/s, mean iterations/frame {res['iters'].mean():.1f}, "
+          f"lambda_temporal {lam_tmp}{'' if has_temporal else ' -- no temporal checkpoint given: pull term off'})")
+    return dict(mpjpe=mpjpe, mpeepe=mpeepe, time=elapsed, frames=n, out=out_path, mean_iters=float(res["iters"].mean()))
+
+
+def evaluate_files(args, paths, opt, encoder, temporal_pack, cfg, raw):
+    """one or more files as sequences in lock-step"""
+    seqs = [prepare_file(args, p, opt, encoder, cfg, raw) for p in paths]
+    results, elapsed, lam_tmp, has_temporal = run_sequences(args, seqs, opt, temporal_pack, cfg)
+    out = []
+    for q, r in zip(seqs, results):
+        if len(seqs) > 1:
+            print(f"Result {q['path']} ------------------------")
+        out.append(finish_file(args, q, r, elapsed, lam_tmp, has_temporal, shared=len(seqs)))
+    return out
+
+
+def evaluate_file(args, input_path, opt, encoder, temporal_pack, cfg, raw):
+    return evaluate_files(args, [input_path], opt, encoder, temporal_pack, cfg, raw)[0]
 
 
 def main(argv=None):
@@ -132,6 +170,9 @@ def main(argv=None):
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--out-dir", default="data")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="directory input: advance all files together, one kernel launch per frame index for all of them "
+                         "(same per-file results; the reference evaluates them one after the other)")
     ap.add_argument("--device", default="cuda:0")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
@@ -150,6 +191,9 @@ def main(argv=None):
     files = [args.input_path]
     if os.path.isdir(args.input_path):
         files = sorted(os.path.join(args.input_path, f) for f in os.listdir(args.input_path) if f.endswith(".bvh"))
+    if args.lockstep and len(files) > 1:
+        print(f"Evaluate {len(files)} files in lock-step ------------------------")
+        return evaluate_files(args, files, opt, encoder, temporal_pack, cfg, raw)
     results = []
     for f in files:
         print(f"Evaluate {f} ------------------------")

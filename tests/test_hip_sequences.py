@@ -161,3 +161,28 @@ def test_eval_drag_cli_on_bvh_clip(tmp_path):
     assert res["frames"] == 240 and os.path.exists(res["out"])
     assert res["mpeepe"] < 0.05 and res["mpjpe"] < 0.08, res  # metres; the paper-level accuracy is a few cm
     assert res["mean_iters"] < 60
+
+
+def test_eval_drag_lockstep_equals_one_file_at_a_time(tmp_path):
+    """--lockstep on a directory: all files advance together (one launch per frame index for all of them) and every
+    file gets exactly the result it gets alone, including a file shorter than the others."""
+    import os
+
+    from dragposer_amd import eval_drag
+    from dragposer_amd.bvh import BVH
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clip = os.path.join(root, "tests", "data", "example_clip.bvh")
+    indir = tmp_path / "in"
+    indir.mkdir()
+    for name, lo, hi in (("a.bvh", 0, 240), ("b.bvh", 60, 200), ("c.bvh", 100, 240)):
+        b = BVH().load(clip)
+        b.motion = b.motion[lo:hi].copy()
+        b.save(str(indir / name))
+    cfg = os.path.join(root, "dragposer_amd", "config", "6_trackers_config.json")
+    alone = eval_drag.main([str(indir), "--config", cfg, "--out-dir", str(tmp_path / "alone")])
+    together = eval_drag.main([str(indir), "--config", cfg, "--out-dir", str(tmp_path / "lockstep"), "--lockstep"])
+    assert [r["frames"] for r in together] == [240, 140, 140]
+    for ra, rt in zip(alone, together):
+        assert ra["frames"] == rt["frames"] and ra["mean_iters"] == rt["mean_iters"]
+        assert open(ra["out"]).read() == open(rt["out"]).read()  # the written BVH files are identical
