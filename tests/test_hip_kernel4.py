@@ -157,3 +157,19 @@ def test_full_size_batches_bit_equal(opt, dev, B):
     auto = opt.optimize(**d, n_iter=50, max_trackers=6)
     assert opt.kernel_geometry()[:2] == ((16, 512) if B <= 4096 else (16, 256))
     np.testing.assert_array_equal(auto["z"].cpu().numpy(), ref["z"])
+
+
+def test_understated_hint_is_memory_safe(opt, dev):
+    """a caller that states max_trackers = 6 but tracks all 22 joints gets the first 16 (the kernel's capacity) used and the
+    rest ignored -- documented, finite, and no out-of-bounds access"""
+    from dragposer_amd.optimizer import to_device_batch
+
+    b = R.synth_inputs(R.OracleModel(), 9000)
+    b["tracked"][:] = 1
+    b["w"][:] = 1.0
+    d = to_device_batch(b, dev)
+    os.environ.pop("DP_KERNEL", None)
+    o = opt.optimize(**d, n_iter=5, max_trackers=6)
+    torch.cuda.synchronize()
+    assert opt.kernel_geometry()[:2] == (16, 256)
+    assert all(torch.isfinite(v).all() for k, v in o.items() if v.dtype == torch.float32)
