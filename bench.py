@@ -212,8 +212,8 @@ def main():
                          "hbm_algorithmic_GBps": B * 1264 / (kern_ms * 1e-3) / 1e9},
             "parity_p99_mm_vs_oracle": err_mm,  # 256 frames x 22 joints vs the C oracle (fp32)
         }
-        if not args.no_cpu_baseline:
-            cpu = {k: v[:64].cpu().numpy() for k, v in batch.items()}
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
+            cpu = {k: v[:1024].cpu().numpy() for k, v in batch.items()}
             res["cpu_baseline"] = cpu_baseline(cpu, N)
         print(json.dumps(res), flush=True)
     if dist is not None:
