@@ -102,6 +102,8 @@ class DragPose:
         wj_h = np.asarray(weights_joints.cpu() if isinstance(weights_joints, torch.Tensor) else weights_joints, dtype=np.float32).reshape(-1, 2)
         key = (mj_h.tobytes(), wj_h.tobytes())
         if key not in self._trk_cache:
+            if len(self._trk_cache) >= 8:  # a caller that keeps changing its tracker set: keep the cache bounded
+                self._trk_cache.pop(next(iter(self._trk_cache)))
             dev, S = self.device, self.S
             if wj_h.shape[0] != mj_h.shape[0]:
                 raise ValueError("target_ee_pos / target_ee_rot / weights_joints must have one row per entry of mask_joints")
