@@ -114,13 +114,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
             lds[L_LT + f16 * 8 + 4 * (wave & 1) + h] = dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
         }
     }
-    if (EARLY && tid < FPB) *(f4*)(lds + L_ES + tid * 8) = f4{1.f, 0.f, 0.f, 1.f};
+    if (EARLY && tid < FPB) { // per-frame early-stop record; frames of waves that sit P3 out count as stopped
+        const float live = (blk0 + (tid & ~1) < nB) ? 1.f : 0.f;
+        *(f4*)(lds + L_ES + tid * 8) = f4{live, 0.f, 0.f, live};
+    }
 
     // ---- P3 per-lane identity (a few integers stay in registers, the float constants are re-read from
     //      LDS every iteration to keep the register budget for the kinematics temporaries)
     const ItemId id = load_item(icg);
     const int gfp = blk0 + pf;
     const bool fvalid = gfp < nB;
+    const bool wave_live = blk0 + 2 * wave < nB; // (uniform) at least one of this wave's two frames exists
     int Emax;
     const unsigned pk = p3_setup<R8>(a, icg, id, lane, it_id, min(gfp, nB - 1), optimise, fr, Emax);
 
@@ -189,7 +193,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dp_optimize_kernel(const KArgs a)
         STAMP(5);
 
         // ================= P3: normalise, FK, loss, backward to gy   (wave-private rows; dp_p3.h)
-        p3_round<R8>(a, id, pk, Emax, icl, yp + pf * S_Y, lds + L_GY + pf * S_Y, pf >= 8, fr, iter, gfp, fvalid, prof, [&]() {
+        // (waves whose two frames both lie beyond the batch sit the phase out: their rows of dL/dy stay zero, and a
+        //  short batch -- one sequence -- does not pay for the SIMD partner's instruction stream)
+        if (wave_live) p3_round<R8>(a, id, pk, Emax, icl, yp + pf * S_Y, lds + L_GY + pf * S_Y, pf >= 8, fr, iter, gfp, fvalid, prof, [&]() {
             if (EARLY) { // root lane: per-frame stop test of the reference's while loop (drag_pose.py:300-304,351-355)
                 const int E = __popc(__float_as_uint(fr.qd[24]));
                 float lp = 0.f, lr = 0.f;

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(K4_NT, 2) void dp_optimize_kernel4(const KArgs a)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int pf = pf0 + 2 * r;
-            p3_round<K4_R>(a, id, pk_[r], Emax_[r], icl, yp + pf * S_Y, lds + K_GY + pf * S_Y, pf >= 8, rows(lds, pf), iter,
+            if (blk0 + (ROUNDS == 2 ? 4 : 2) * wave + 2 * r < nB) // (uniform) at least one of the round's two frames exists
+                p3_round<K4_R>(a, id, pk_[r], Emax_[r], icl, yp + pf * S_Y, lds + K_GY + pf * S_Y, pf >= 8, rows(lds, pf), iter,
                            blk0 + pf, blk0 + pf < nB && pf < FR, prof, []() {});
             if (ROUNDS > 1) __builtin_amdgcn_sched_barrier(0); // keep the rounds apart: interleaving them doubles the live temporaries
         }
