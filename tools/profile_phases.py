@@ -27,8 +27,11 @@ torch.cuda.synchronize()
 fpb, tpb, _ = opt.kernel_geometry()
 grid = (B + fpb - 1) // fpb
 print(f"kernel: {fpb} frames / {tpb} threads per workgroup, {grid} workgroups")
-p = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20)[:, :17].astype(np.float64) / N
-tot = p.sum(1)
+raw = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20).astype(np.float64) / N
+p = raw[:, :17]
+tot = raw.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:26s} {p[:, i].mean():8.0f}  {100 * p[:, i].mean() / tot.mean():5.1f}%")
+if raw[:, 17:].any():  # ad-hoc sub-stamps (slots 17..19) of an experiment
+    print("  extra stamps 16..19:", " ".join(f"{raw[:, i].mean():.0f}" for i in range(16, 20)))
