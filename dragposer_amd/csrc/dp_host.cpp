@@ -12,6 +12,7 @@
 #include "../../include/dragposer.h"
 #include "dp_kernel.h"
 #include "dp_sequence.h"
+#include "dp_w4.h"
 
 using namespace dpl;
 
@@ -20,6 +21,8 @@ struct dp_ctx {
     int n_cu = 256;
     float* d_wfrag = nullptr;
     float* d_bias = nullptr;
+    float* d_w4img = nullptr;
+    float* d_w4bias = nullptr;
     ItemConst* d_items = nullptr;
     dp_folded folded;
     std::vector<unsigned> smask;
@@ -210,6 +213,52 @@ extern "C" int dp_debug_pack(const dp_folded* f, const int* parents, float* wfra
     return DP_OK;
 }
 
+// host-only, exported for the CPU tests: weight image of the wave-private kernel (dp_w4.h)
+//   img [N_GROUPS][64][4]: step s = 4 g + m of lane l at img[(g * 64 + l) * 4 + m];  bias [4][64]
+// Rows of layer 2 / columns of its transpose are indexed by P3 item: row 4 * item + c is channel c of joint `item`
+// (items 0..21), of the root displacement (22) or of a virtual copy of a joint with a second / third child (23..25).
+static int w4_src_row(const ItemPlan& pl, int item, int c)
+{ // row of A2 that feeds channel c of `item`, or -1
+    if (item < NJ) return 4 * item + c;
+    if (item == ITEM_DISP) return 4 * ITEM_DISP + c; // 88..91 (91: the decoder's unused fourth displacement channel)
+    const int v = item - ITEM_VIRT0;
+    if (v >= 0 && v < pl.nvirt) return 4 * pl.virt_parent[v] + c;
+    return -1;
+}
+
+extern "C" int dp_debug_pack_w4(const dp_folded* f, const int* parents, float* img, float* bias)
+{
+    if (!f || !parents || !img || !bias) return DP_ERR_INVALID;
+    ItemPlan pl;
+    std::string err;
+    int rc = plan_items(parents, pl, err);
+    if (rc != DP_OK) return fail(nullptr, rc, err);
+    std::memset(img, 0, sizeof(float) * dpw4::IMG_FLOATS);
+    std::memset(bias, 0, sizeof(float) * dpw4::BIAS_FLOATS);
+    auto put = [&](int step, int lane, float v) { img[((step >> 2) * 64 + lane) * 4 + (step & 3)] = v; };
+    for (int l = 0; l < 64; ++l) {
+        for (int k = 0; k < 24; ++k) put(dpw4::S_L0 + k, l, l < 40 ? f->A0[l * 24 + k] : 0.f);
+        for (int k = 0; k < 40; ++k) put(dpw4::S_L1 + k, l, l < 60 ? f->A1[l * 40 + k] : 0.f);
+        const int ra = w4_src_row(pl, l >> 2, l & 3), rb = w4_src_row(pl, dpw4::ITEMS_A + (l >> 2), l & 3);
+        for (int k = 0; k < 60; ++k) {
+            put(dpw4::S_L2A + k, l, ra >= 0 ? f->A2[ra * 60 + k] : 0.f);
+            put(dpw4::S_L2B + k, l, rb >= 0 ? f->A2[rb * 60 + k] : 0.f);
+        }
+        for (int k = 0; k < 104; ++k) { // column k = channel k & 3 of item k >> 2 of dL/dy; the displacement's 4th channel carries nothing
+            const int r = w4_src_row(pl, k >> 2, k & 3);
+            const bool dead = (k >> 2) == ITEM_DISP && (k & 3) == 3;
+            put(dpw4::S_B2 + k, l, (l < 60 && r >= 0 && !dead) ? f->A2[r * 60 + l] : 0.f);
+        }
+        for (int k = 0; k < 60; ++k) put(dpw4::S_B1 + k, l, l < 40 ? f->A1[k * 40 + l] : 0.f);
+        for (int k = 0; k < 40; ++k) put(dpw4::S_B0 + k, l, l < 24 ? f->A0[k * 24 + l] : 0.f);
+        bias[l] = l < 40 ? f->c0[l] : 0.f;
+        bias[64 + l] = l < 60 ? f->b1[l] : 0.f;
+        bias[128 + l] = ra >= 0 ? f->b2[ra] : 0.f;
+        bias[192 + l] = rb >= 0 ? f->b2[rb] : 0.f;
+    }
+    return DP_OK;
+}
+
 // host-only, exported for the CPU tests: P3 per-item constants [32]
 extern "C" int dp_debug_items(const dp_model* m, void* out_items /* 32 x 128 B */)
 {
@@ -299,7 +348,9 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
     ctx->smask.assign(NWAVE * NGEMM, 0u);
     std::vector<ItemConst> items(32);
+    std::vector<float> w4img(dpw4::IMG_FLOATS), w4bias(dpw4::BIAS_FLOATS);
     if (rc == DP_OK) rc = dp_debug_pack(&ctx->folded, model->parents, wfrag.data(), bfrag.data(), ctx->smask.data());
+    if (rc == DP_OK) rc = dp_debug_pack_w4(&ctx->folded, model->parents, w4img.data(), w4bias.data());
     if (rc == DP_OK) rc = dp_debug_items(model, items.data());
     if (rc != DP_OK) { delete ctx; return rc; }
     int prev = 0;
@@ -308,13 +359,17 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_wfrag, wfrag.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_bias, bfrag.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_items, items.size() * sizeof(ItemConst));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4img, w4img.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4bias, w4bias.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_w4img, w4img.data(), w4img.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_w4bias, w4bias.data(), w4bias.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_wfrag, wfrag.data(), wfrag.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_bias, bfrag.data(), bfrag.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_items, items.data(), items.size() * sizeof(ItemConst), hipMemcpyHostToDevice);
     hipSetDevice(prev);
     if (e != hipSuccess) {
         std::string msg = std::string("dp_create: ") + hipGetErrorString(e);
-        hipFree(ctx->d_wfrag); hipFree(ctx->d_bias); hipFree(ctx->d_items);
+        hipFree(ctx->d_wfrag); hipFree(ctx->d_bias); hipFree(ctx->d_items); hipFree(ctx->d_w4img); hipFree(ctx->d_w4bias);
         delete ctx;
         return fail(nullptr, DP_ERR_DEVICE, msg);
     }
@@ -328,6 +383,8 @@ extern "C" int dp_destroy(dp_ctx* ctx)
     hipFree(ctx->d_wfrag);
     hipFree(ctx->d_bias);
     hipFree(ctx->d_items);
+    hipFree(ctx->d_w4img);
+    hipFree(ctx->d_w4bias);
     delete ctx;
     return DP_OK;
 }
@@ -372,9 +429,9 @@ extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
 extern "C" int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes)
 { // of the kernel the context's last launch used (the 8-wave kernel before any launch)
     const int k = ctx ? ctx->last_kernel : 0;
-    if (frames_per_block) *frames_per_block = k == 41 ? 8 : FPB;
-    if (threads_per_block) *threads_per_block = (k == 41 || k == 42) ? 256 : NTHREADS;
-    if (lds_bytes) *lds_bytes = (k == 41 || k == 42) ? dp_kernel4_lds_bytes() : dp_kernel_lds_bytes();
+    if (frames_per_block) *frames_per_block = k == 41 ? 8 : k == 4 ? dp_w4_frames_per_block() : FPB;
+    if (threads_per_block) *threads_per_block = (k == 41 || k == 42 || k == 4) ? 256 : NTHREADS;
+    if (lds_bytes) *lds_bytes = k == 4 ? dp_w4_lds_bytes() : (k == 41 || k == 42) ? dp_kernel4_lds_bytes() : dp_kernel_lds_bytes();
     return DP_OK;
 }
 
@@ -384,6 +441,8 @@ static void fill_model_args(const dp_ctx* ctx, KArgs& k)
     k.wfrag = ctx->d_wfrag;
     k.bias = ctx->d_bias;
     k.items = ctx->d_items;
+    k.w4img = ctx->d_w4img;
+    k.w4bias = ctx->d_w4bias;
     std::memcpy(k.smask, ctx->smask.data(), sizeof(k.smask));
 }
 
@@ -407,7 +466,8 @@ static int pick_kernel(const dp_ctx* ctx, const KArgs& k, int max_trackers)
     const bool k4_ok = !k.early_stop && (k.mode == 1 || (max_trackers > 0 && max_trackers <= dp_kernel4_max_trackers()));
     if (k4_ok && k.n_frames > 16 * ctx->n_cu) choice = 42;
     if (const char* e = std::getenv("DP_KERNEL")) {
-        if (!std::strcmp(e, "8")) choice = 8;
+        if (!std::strcmp(e, "w4") && !k.early_stop) choice = 4;
+        else if (!std::strcmp(e, "8")) choice = 8;
         else if (k4_ok && !std::strcmp(e, "4x1")) choice = 41;
         else if (k4_ok && !std::strcmp(e, "4x2")) choice = 42;
     }
@@ -418,7 +478,9 @@ static int launch(dp_ctx* ctx, KArgs& k, void* stream, int max_trackers = 0)
 {
     const int choice = pick_kernel(ctx, k, max_trackers);
     ctx->last_kernel = choice;
-    hipError_t e = choice == 8 ? dp_launch_optimize(&k, (hipStream_t)stream) : dp_launch_optimize4(&k, choice - 40, (hipStream_t)stream);
+    hipError_t e = choice == 8   ? dp_launch_optimize(&k, (hipStream_t)stream)
+                   : choice == 4 ? dp_launch_w4(&k, (hipStream_t)stream)
+                                 : dp_launch_optimize4(&k, choice - 40, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
     return DP_OK;
 }

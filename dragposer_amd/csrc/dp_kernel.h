@@ -19,6 +19,8 @@ struct KArgs {
     const float* wfrag;          // [NWAVE][W_REGS][64]  per-wave, per-lane MFMA A operands
     const float* bias;           // [2][64] padded bias rows of L0 (c0) and L1 (b1)
     const dpl::ItemConst* items; // [32]
+    const float* w4img;          // [dpw4::N_GROUPS][64][4]  weight image of the wave-private kernel (dp_w4.h)
+    const float* w4bias;         // [4][64] accumulator seeds of L0, L1, L2A, L2B
     // batch (device)
     const float *z0, *z_tgt, *cur_rot, *tgt_pos, *tgt_rot, *w;
     const unsigned char* tracked;
@@ -41,3 +43,7 @@ extern "C" int dp_kernel_lds_bytes(void);
 extern "C" hipError_t dp_launch_optimize4(const KArgs* args, int rounds, hipStream_t stream);
 extern "C" int dp_kernel4_lds_bytes(void);
 extern "C" int dp_kernel4_max_trackers(void);
+// dp_w4.hip: wave-private kernel, 4 frames per wave, no workgroup barrier inside the loop
+extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream);
+extern "C" int dp_w4_lds_bytes(void);
+extern "C" int dp_w4_frames_per_block(void);
