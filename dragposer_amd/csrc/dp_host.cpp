@@ -23,6 +23,7 @@ struct dp_ctx {
     float* d_bias = nullptr;
     float* d_w4img = nullptr;
     float* d_w4bias = nullptr;
+    dpw4::Pair* d_w4pairs = nullptr;
     ItemConst* d_items = nullptr;
     dp_folded folded;
     std::vector<unsigned> smask;
@@ -239,14 +240,16 @@ extern "C" int dp_debug_pack_w4(const dp_folded* f, const int* parents, float* i
     for (int l = 0; l < 64; ++l) {
         for (int k = 0; k < 24; ++k) put(dpw4::S_L0 + k, l, l < 40 ? f->A0[l * 24 + k] : 0.f);
         for (int k = 0; k < 40; ++k) put(dpw4::S_L1 + k, l, l < 60 ? f->A1[l * 40 + k] : 0.f);
-        const int ra = w4_src_row(pl, l >> 2, l & 3), rb = w4_src_row(pl, dpw4::ITEMS_A + (l >> 2), l & 3);
+        const int ib = dpw4::item_of(1, l >> 2);
+        const int ra = w4_src_row(pl, dpw4::item_of(0, l >> 2), l & 3), rb = ib >= 0 ? w4_src_row(pl, ib, l & 3) : -1;
         for (int k = 0; k < 60; ++k) {
             put(dpw4::S_L2A + k, l, ra >= 0 ? f->A2[ra * 60 + k] : 0.f);
             put(dpw4::S_L2B + k, l, rb >= 0 ? f->A2[rb * 60 + k] : 0.f);
         }
-        for (int k = 0; k < 104; ++k) { // column k = channel k & 3 of item k >> 2 of dL/dy; the displacement's 4th channel carries nothing
-            const int r = w4_src_row(pl, k >> 2, k & 3);
-            const bool dead = (k >> 2) == ITEM_DISP && (k & 3) == 3;
+        for (int k = 0; k < 104; ++k) { // column k = channel k & 3 of an item of dL/dy (side A quads 0..15, then side B quads 1..10);
+            const int item = k < 64 ? dpw4::item_of(0, k >> 2) : dpw4::item_of(1, dpw4::B2_ABID0_B + ((k - 64) >> 2));
+            const int r = w4_src_row(pl, item, k & 3);
+            const bool dead = item == ITEM_DISP && (k & 3) == 3; // the displacement's 4th channel carries nothing
             put(dpw4::S_B2 + k, l, (l < 60 && r >= 0 && !dead) ? f->A2[r * 60 + l] : 0.f);
         }
         for (int k = 0; k < 60; ++k) put(dpw4::S_B1 + k, l, l < 40 ? f->A1[k * 40 + l] : 0.f);
@@ -256,6 +259,39 @@ extern "C" int dp_debug_pack_w4(const dp_folded* f, const int* parents, float* i
         bias[128 + l] = ra >= 0 ? f->b2[ra] : 0.f;
         bias[192 + l] = rb >= 0 ? f->b2[rb] : 0.f;
     }
+    return DP_OK;
+}
+
+extern "C" int dp_debug_items(const dp_model* m, void* out_items);
+
+// host-only, exported for the CPU tests: kinematics constants of the wave-private kernel, one dpw4::Pair per lane quad
+extern "C" int dp_debug_pairs_w4(const dp_model* m, void* out_pairs /* 16 x 144 B */)
+{
+    if (!model_ptrs_ok(m) || !out_pairs) return fail(nullptr, DP_ERR_INVALID, "dp_debug_pairs_w4: NULL pointer");
+    std::vector<ItemConst> items(32);
+    int rc = dp_debug_items(m, items.data());
+    if (rc != DP_OK) return rc;
+    dpw4::Pair* pr = (dpw4::Pair*)out_pairs;
+    std::memset(pr, 0, sizeof(dpw4::Pair) * 16);
+    for (int b = 0; b < 16; ++b)
+        for (int s = 0; s < 2; ++s) {
+            dpw4::Pair& p = pr[b];
+            const int item = dpw4::item_of(s, b);
+            p.item[s] = item;
+            p.kind[s] = KIND_IDLE;
+            p.mu[0][s] = 1.f; // idle: a unit quaternion, whatever the (zero) decoder channels say
+            p.sgn[s] = 1.f;
+            p.bone_slot[s] = SLOT_TRASH + ((2 * b + s) & 7);
+            if (item < 0) continue;
+            const ItemConst& c = items[item];
+            p.kind[s] = c.kind;
+            if (c.kind == KIND_IDLE) continue;
+            for (int k = 0; k < 4; ++k) { p.sd[k][s] = c.sd[k]; p.mu[k][s] = c.mu[k]; }
+            for (int k = 0; k < 3; ++k) p.off[k][s] = c.ch_off[k];
+            p.bone_slot[s] = c.ch_id;
+            p.ch_sub[s] = c.ch_sub;
+            if (c.kind == KIND_ROOT) { p.sgn[s] = -1.f; p.rho[s] = 1.f; p.ch_sub[s] = (1u << NJ) - 1u; }
+        }
     return DP_OK;
 }
 
@@ -352,6 +388,8 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     if (rc == DP_OK) rc = dp_debug_pack(&ctx->folded, model->parents, wfrag.data(), bfrag.data(), ctx->smask.data());
     if (rc == DP_OK) rc = dp_debug_pack_w4(&ctx->folded, model->parents, w4img.data(), w4bias.data());
     if (rc == DP_OK) rc = dp_debug_items(model, items.data());
+    std::vector<dpw4::Pair> pairs(16);
+    if (rc == DP_OK) rc = dp_debug_pairs_w4(model, pairs.data());
     if (rc != DP_OK) { delete ctx; return rc; }
     int prev = 0;
     hipGetDevice(&prev);
@@ -361,6 +399,8 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_items, items.size() * sizeof(ItemConst));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4img, w4img.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4bias, w4bias.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4pairs, pairs.size() * sizeof(dpw4::Pair));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_w4pairs, pairs.data(), pairs.size() * sizeof(dpw4::Pair), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w4img, w4img.data(), w4img.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w4bias, w4bias.data(), w4bias.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_wfrag, wfrag.data(), wfrag.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -369,7 +409,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     hipSetDevice(prev);
     if (e != hipSuccess) {
         std::string msg = std::string("dp_create: ") + hipGetErrorString(e);
-        hipFree(ctx->d_wfrag); hipFree(ctx->d_bias); hipFree(ctx->d_items); hipFree(ctx->d_w4img); hipFree(ctx->d_w4bias);
+        hipFree(ctx->d_wfrag); hipFree(ctx->d_bias); hipFree(ctx->d_items); hipFree(ctx->d_w4img); hipFree(ctx->d_w4bias); hipFree(ctx->d_w4pairs);
         delete ctx;
         return fail(nullptr, DP_ERR_DEVICE, msg);
     }
@@ -385,6 +425,7 @@ extern "C" int dp_destroy(dp_ctx* ctx)
     hipFree(ctx->d_items);
     hipFree(ctx->d_w4img);
     hipFree(ctx->d_w4bias);
+    hipFree(ctx->d_w4pairs);
     delete ctx;
     return DP_OK;
 }
@@ -443,6 +484,7 @@ static void fill_model_args(const dp_ctx* ctx, KArgs& k)
     k.items = ctx->d_items;
     k.w4img = ctx->d_w4img;
     k.w4bias = ctx->d_w4bias;
+    k.w4pairs = ctx->d_w4pairs;
     std::memcpy(k.smask, ctx->smask.data(), sizeof(k.smask));
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dp_layout.h"
+#include "dp_w4.h"
 
 struct AdamTab { // per-iteration scalars torch's single-tensor Adam computes in Python doubles
     float step[dpl::MAX_ITERS]; // lr / (1 - beta1^t)
@@ -21,6 +22,7 @@ struct KArgs {
     const dpl::ItemConst* items; // [32]
     const float* w4img;          // [dpw4::N_GROUPS][64][4]  weight image of the wave-private kernel (dp_w4.h)
     const float* w4bias;         // [4][64] accumulator seeds of L0, L1, L2A, L2B
+    const dpw4::Pair* w4pairs;   // [16] kinematics constants per lane quad
     // batch (device)
     const float *z0, *z_tgt, *cur_rot, *tgt_pos, *tgt_rot, *w;
     const unsigned char* tracked;

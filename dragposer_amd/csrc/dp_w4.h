@@ -23,9 +23,9 @@ constexpr int FPW = 4; // frames per wave
 // steps (K = 1 each) of the weight image, in program order; every product's count is a multiple of 4
 constexpr int S_L0 = 0;            // 24: rows = 40 channels of a0
 constexpr int S_L1 = S_L0 + 24;    // 40: rows = 60 channels of a1
-constexpr int S_L2A = S_L1 + 40;   // 60: rows = items 0..15 of y (4 channels each)
-constexpr int S_L2B = S_L2A + 60;  // 60: rows = items 16..31 of y
-constexpr int S_B2 = S_L2B + 60;   // 104: K = 4 channels of items 0..25 of dL/dy, rows = 60 channels of d1
+constexpr int S_L2A = S_L1 + 40;   // 60: rows = side-A items of y (4 channels each)
+constexpr int S_L2B = S_L2A + 60;  // 60: rows = side-B items of y
+constexpr int S_B2 = S_L2B + 60;   // 104: K = 4 channels of the 16 side-A items, then of side-B quads 1..10; rows = 60 channels of d1
 constexpr int S_B1 = S_B2 + 104;   // 60: rows = 40 channels of d0
 constexpr int S_B0 = S_B1 + 60;    // 40: rows = 24 channels of dL/dz
 constexpr int N_STEPS = S_B0 + 40; // 388
@@ -35,6 +35,25 @@ constexpr int IMG_FLOATS = N_GROUPS * 64 * 4;
 // bias image [4][64]: L0, L1, L2A, L2B rows (the accumulators start from it)
 constexpr int BIAS_FLOATS = 4 * 64;
 
-constexpr int ITEMS_A = 16; // items 0..15 ride in block A of layer 2, items 16..31 in block B
+// Kinematics items of a lane quad b: side A = item b (the 16 joints 0..15), side B = item 15 + b for b = 1..10 (joints
+// 16..21, the root displacement 22, virtual child-bone copies 23..25); quad 0's side B is idle, so that the root (side A
+// of quad 0) shares its lanes with nothing.  Block A / B of layer 2 and the K order of its transpose follow this map.
+constexpr int ITEMS_A = 16;
+DP_HD constexpr int item_of(int side, int b) { return side == 0 ? b : (b >= 1 && b <= 10 ? 15 + b : -1); }
+constexpr int B2_GROUPS_A = 16, B2_GROUPS_B = 10, B2_ABID0_B = 1; // bL2: K groups of side A (ABID 0..15), side B (ABID 1..10)
+
+// per-quad constants of the two items, side A / side B interleaved (the kernel keeps them as packed register pairs)
+struct Pair {
+    float sd[4][2], mu[4][2]; // de-normalisation of the item's 4 decoder channels (idle: 0 / (1,0,0,0))
+    float off[3][2];          // offset of the child bone the item handles (zero when none)
+    float sgn[2];             // +1: dL/dq = (0, 2 tau) (x) q;  -1 (root): q (x) (0, 2 tau)
+    float rho[2];             // 1 (root): tau = sum of the trackers' root torques; 0: tau = bone x S + own torque
+    int item[2];              // item id, -1 idle
+    int kind[2];              // dpl::KIND_*
+    int bone_slot[2];         // bone slot the item writes (child joint id, or a trash slot)
+    unsigned ch_sub[2];       // trackers summed by the item: subtree of its child (root, displacement: every joint)
+    int pad[2];
+};
+static_assert(sizeof(Pair) == 36 * 4, "Pair is 36 words");
 
 } // namespace dpw4

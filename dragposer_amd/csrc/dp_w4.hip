@@ -1,17 +1,28 @@
 // dp_w4.hip -- wave-private variant of the fused latent-optimisation kernel for gfx950 (MI355X).
 //
-// Same mathematics as dp_kernel.hip (reference: DragPose.run's while loop, python/src/drag_pose.py:296-355), other
+// Same problem as dp_kernel.hip (reference: DragPose.run's while loop, python/src/drag_pose.py:296-355), other
 // decomposition: ONE wavefront owns FOUR frames from the first decoder layer to the Adam step, so an iteration has no
 // workgroup barrier and no cross-wave traffic at all.
 //   * Decoder forward / backward: v_mfma_f32_4x4x1_16b_f32 with the A-block broadcast (dp_w4.h): a step is a rank-1
 //     update of a 64-channel x 4-frame tile; activations stay in registers between layers (a 4x4 register <-> lane
-//     transpose inside lane quads turns a product's result into the next product's operand); weights are shared by
-//     the waves of a workgroup and streamed from LDS, one ds_read_b128 per four steps.
-//   * Kinematics (P3): lane 4b+i = item b of frame i (two rounds: items 0..15, 16..31); the cross-item traffic of a
-//     frame (bones, tracker gradients) goes through that frame's own LDS block, written and read by this wave only.
+//     transpose inside lane quads turns a product's result into the next product's operand).  The weights of L0, L1,
+//     L2 and bL1 stay resident in the accumulator half of the register file for the whole launch; those of bL2 and bL0
+//     are streamed from LDS (shared by the waves of a workgroup), requested a phase ahead of their use.
+//   * Kinematics: three stages per iteration, two wave-level LDS exchanges between them, all inside the wave.
+//       J  lane 4b+i = the two items of quad b (dp_w4.h) of frame i, both in one packed (v_pk_*) instruction stream:
+//          de-normalise, normalise, root-frame bone of the item's child (quaternion sandwich, no matrix);
+//       T  lane 4u+i = tracker of rank u of frame i: root-frame position from the bones, position error, rotation error
+//          as a quaternion product, their gradients as TORQUES (3-vectors in the tangent space of the rotations);
+//       G  lanes as in J: subtree sums of the trackers' gradients, torque -> dL/dq = (0, 2 tau) (x) q -> dL/dy.
+//     The formulation is the reference's loss (drag_pose.py:66-194) and the gradient autograd derives from it, restated
+//     where that is cheaper and equal in real arithmetic: rotations compose as M(cur (x) q) =
+//     M(cur) M(q), so the loop works in the frame of `cur_rot` with targets rotated once; |M - T|_F^2 = 8 (1 - <q_M,
+//     q_T>^2) for rotations; and the gradient of a normalised quaternion lives in its tangent space, where it is the
+//     torque of the loss.  Target rotations must therefore be rotation matrices (the reference builds them with
+//     to_matrix from unit quaternions, eval_drag.py:199, run_drag.py:136).
 //   * Adam: element-wise in the layout the last product leaves dL/dz in (lane = latent dim, register = frame).
-// A workgroup is NW waves that share nothing but the weight image; grid = ceil(B / (4 NW)).
-#include "dp_p3.h"
+// A workgroup is NW waves that share nothing but the streamed weight image; grid = ceil(B / (4 NW)).
+#include "dp_device.h"
 #include "dp_w4.h"
 #include <utility>
 
@@ -22,42 +33,64 @@ template <int N, class F> DEV void static_for(F&& f) { static_for_impl(f, std::m
 
 // ------------------------------------------------------------------------------------------------
 // LDS map (floats)
-constexpr int W4_R = 24;                        // tracker capacity per frame (>= NJ: every joint may carry one)
-// one block per frame: bones | tracker gradients | d/d(qw) contributions | loss terms | qd row | tracker inputs | z rows
-constexpr int FB_BONE = 0;                      // [32][4]
-constexpr int FB_GPC = FB_BONE + 128;           // [R][4]
-constexpr int FB_CQ = FB_GPC + 4 * W4_R;        // [R][4]
-constexpr int FB_LP = FB_CQ + 4 * W4_R;         // [R][2]
-constexpr int FB_QD = FB_LP + 2 * W4_R;         // [QD_S]  (dp_p3.h)
-constexpr int FB_TRK = FB_QD + QD_S;            // [4][R][4]
-constexpr int FB_ZPRE = FB_TRK + 16 * W4_R;     // [24] latent of the last forward pass (epilogue only)
-constexpr int FB_ZT = FB_ZPRE + LAT;            // [24] z_tgt (epilogue only)
+constexpr int W4_R = 24; // tracker capacity per frame (>= NJ: every joint may carry one)
+// one block per frame
+constexpr int FB_QS = 0;                     // [32][4] unit quaternion by item id; 22: root displacement (x,y,z,-); 30: (1,0,0,0); 31: trash
+constexpr int FB_BN = FB_QS + 128;           // [32][4] root-frame bone by child joint id; SLOT_ZERO: zero; 24..31: trash
+constexpr int FB_GP = FB_BN + 128;           // [R][4]  tracker position gradient by rank
+constexpr int FB_RT = FB_GP + 4 * W4_R;      // [R][4]  tracker torque on the root by rank
+constexpr int FB_WT = FB_RT + 4 * W4_R;      // [32][4] own rotation torque by joint id (zero where untracked); 30: zero; 31: trash
+constexpr int FB_LP = FB_WT + 128;           // [R][2]  tracker loss terms (last iteration)
+constexpr int FB_TI = FB_LP + 2 * W4_R;      // [3][R][4] tracker inputs by rank: tp', cgp | qT' | k8, clp, clr8, joint
+constexpr int FB_ZPRE = FB_TI + 12 * W4_R;   // [24] latent of the last forward pass (epilogue only)
+constexpr int FB_ZT = FB_ZPRE + LAT;         // [24] z_tgt (epilogue only)
 constexpr int FB_END = FB_ZT + LAT;
+constexpr int QS_DISP = ITEM_DISP, QS_IDENT = 30, QS_TRASH = 31, WT_ZERO = 30, WT_TRASH = 31;
 // the four frames of a wave sit in the four lanes of every quad: block stride = 16 banks (mod 64) apart, so that the
 // quad's 16-byte accesses to the same row of four blocks never share a bank
 constexpr int FB_STRIDE = ((FB_END - 16 + 63) / 64) * 64 + 16;
-static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_QD % 4 == 0 && FB_TRK % 4 == 0 && FB_ZPRE % 4 == 0, "frame block layout");
+static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && FB_TI % 4 == 0 && FB_ZPRE % 4 == 0, "frame block layout");
 
-constexpr int L_IMG = 0;                        // weight image [N_GROUPS][64][4]
-constexpr int L_ITEM = L_IMG + IMG_FLOATS;      // item constants, SoA: sd[32][4] | mu[32][4] | child offset[32][4]
-constexpr int L_FR = L_ITEM + 3 * 32 * 4;       // frame blocks [NW * 4][FB_STRIDE]
+constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26, GR_B0 = S_B0 / 4, NG_B0 = 10; // streamed products: first group, groups
+constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
+constexpr int L_IMG0 = L_IMG2 + NG_B2 * 256;    // bL0 image [10][64][4]
+constexpr int L_FR = L_IMG0 + NG_B0 * 256;      // frame blocks [NW * 4][FB_STRIDE]
 template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE; }
 
 // ------------------------------------------------------------------------------------------------
-template <int ABID> DEV f4 mfma_bc(float x, float w, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(x, w, c, 4, ABID, 0); }
+// One group = four K-steps on two accumulators: step m multiplies x[m] (channel 4 ABID + m of the X-layout operand, block
+// ABID broadcast to all 16 blocks) with the weight register w[m].  Written as ONE asm statement so that the operand
+// classes are ours: weights the kernel keeps resident live in the ACCUMULATOR half of the register file ("a": an MFMA
+// reads its B operand from either half; the kinematics arithmetic cannot use that half anyway), streamed weights and the
+// accumulators in the vector half.  Hazards the compiler would pad for a builtin: a dependent accumulate (SrcC) needs 2
+// wait states behind a 2-pass MFMA -> the s_nop between the pairs; the readers of the result: chain_end().
+#define W4_GROUP_ASM(WC)                                                                                                  \
+    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%10\n\t"                                           \
+                 "s_nop 0\n\t"                                                                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"                                           \
+                 "s_nop 0"                                                                                                \
+                 : "+v"(acc0), "+v"(acc1)                                                                                 \
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
+template <int ABID> DEV void group_a(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP_ASM("a"); }
+template <int ABID> DEV void group_v(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP_ASM("v"); }
+// a VALU result (transpose, kinematics) feeding the first MFMA of a chain / the chain's result feeding the VALU
+DEV void chain_begin() { asm volatile("s_nop 1"); }
+DEV void chain_end(f4& acc0, f4& acc1) { asm volatile("s_nop 3" : "+v"(acc0), "+v"(acc1)); }
 
-// NG groups of four K-steps: step 4g+m multiplies channel 4(ABID0+g)+m of the X-layout operand `x` with the weight
-// image w[g] (one ds_read_b128 per lane and group); two accumulators keep the 8-cycle issue rate
-template <int NG, int ABID0> DEV void chain(f4& acc0, f4& acc1, const f4& x, const f4* w)
+// NG groups from resident weights (accumulator registers) / from weights in vector registers
+template <int NG, int ABID0> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv)
 {
-    static_for<NG>([&](auto gi) {
-        constexpr int g = decltype(gi)::value;
-        const f4 wv = w[g * 64];
-        acc0 = mfma_bc<ABID0 + g>(x[0], wv[0], acc0);
-        acc1 = mfma_bc<ABID0 + g>(x[1], wv[1], acc1);
-        acc0 = mfma_bc<ABID0 + g>(x[2], wv[2], acc0);
-        acc1 = mfma_bc<ABID0 + g>(x[3], wv[3], acc1);
-    });
+    static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; group_a<ABID0 + g>(acc0, acc1, x, wv[g]); });
+}
+template <int NG, int ABID0> DEV void chain_v(f4& acc0, f4& acc1, const f4& x, const f4* wv)
+{
+    static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; group_v<ABID0 + g>(acc0, acc1, x, wv[g]); });
+}
+template <int NG> DEV void load_w(f4 (&wv)[NG], const f4* w)
+{
+    static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; wv[g] = w[g * 64]; });
 }
 
 // D <-> X: transpose of (register index, lane-in-quad).  Two exchange stages (lane ^ 1, lane ^ 2), each a select whose
@@ -92,258 +125,285 @@ DEV void quad_transpose(f4& r)
 }
 
 DEV f4 splat(float v) { return f4{v, v, v, v}; }
+DEV f2 splat2(float v) { return f2{v, v}; }
 
 // ------------------------------------------------------------------------------------------------
-// Kinematics, lane = (item, frame).  The arithmetic of every item is that of dp_p3.h::p3_round, cut at its two
-// wave-level exchanges into three stages, because the two rounds of a wave (items 0..15, 16..31) share the frames'
-// LDS rows: both rounds finish a stage before either starts the next.
-struct P3S { // what an item keeps in registers from one stage to the next
-    Q4 q;
-    float inv;
-    M3 M, gM;
-    f4 sd, cv, t0, t1, t2, t3;
+// Kinematics.  Quaternions are (w, v) = (w, x, y, z), Hamilton; R(q) a = a + 2 (w (v x a) + v x (v x a)) is the rotation
+// to_matrix_4 (utils.py:49-74) encodes for unit q.
+struct PairC { // loop-invariant constants of my quad's two items, side A | side B packed (registers)
+    f2 sd[4], mu[4], off[3], sgn, rho, sel[6];
+    unsigned subA, subB; // tracker subsets of the two items (general path: more than 6 trackers in a frame)
+    int qsA, qsB;        // float index of my items' quaternion slots in the frame block
+    int bnA, bnB;        //                          child-bone slots
+    int wtA, wtB;        //                          own-torque slots
+    int tab;             // FB_RT on the root's quad, FB_GP elsewhere: the table my items sum over the trackers
+    int kindB;           // KIND_* of side B (side A is always a joint)
+    int itemA, itemB;    // item ids (-1: idle)
 };
 
-template <int R>
-DEV unsigned w4_setup(const KArgs& a, const ItemConst* icg, const ItemId& id, int item, unsigned tmask, int gf, bool optimise,
-                      const FrameRows<R>& fr)
+struct TRec { // a tracker as its T-stage lane sees it
+    bool act;
+    int qs, wt, rank;  // float index of the tracked joint's quaternion slot / own-torque slot; rank
+    unsigned plo, phi; // bone slots on the path root -> joint (dp_layout.h: 7 x 5 bits)
+    V3 tp;             // target position in the frame of cur_rot
+    Q4 qT;             // target rotation in the frame of cur_rot
+    float cgp, clp, k8, clr8; // 2 w_pos / (3E), w_pos / (3E), -8 lam w_rot / (9E), 8 lam w_rot / (9E)
+};
+
+DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DEV V3 rot_conj(Q4 q, V3 a)
+{ // R(conj q) a
+    const V3 v = {q.x, q.y, q.z};
+    const V3 t = cross(v, a), c = cross(v, t);
+    return {a.x + 2.f * (c.x - q.w * t.x), a.y + 2.f * (c.y - q.w * t.y), a.z + 2.f * (c.z - q.w * t.z)};
+}
+
+DEV Q4 quat_from_rotmat(const float* m)
+{ // row-major 3x3 rotation -> unit quaternion (Shepperd's branches; once per tracker, before the loop)
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    const float tr = m00 + m11 + m22;
+    Q4 q;
+    if (tr > 0.f) {
+        const float s = sqrtf(tr + 1.f) * 2.f;
+        q = {0.25f * s, (m21 - m12) / s, (m02 - m20) / s, (m10 - m01) / s};
+    } else if (m00 > m11 && m00 > m22) {
+        const float s = sqrtf(1.f + m00 - m11 - m22) * 2.f;
+        q = {(m21 - m12) / s, 0.25f * s, (m01 + m10) / s, (m02 + m20) / s};
+    } else if (m11 > m22) {
+        const float s = sqrtf(1.f + m11 - m00 - m22) * 2.f;
+        q = {(m02 - m20) / s, (m01 + m10) / s, 0.25f * s, (m12 + m21) / s};
+    } else {
+        const float s = sqrtf(1.f + m22 - m00 - m11) * 2.f;
+        q = {(m10 - m01) / s, (m02 + m20) / s, (m12 + m21) / s, 0.25f * s};
+    }
+    const float n = 1.f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    return {q.w * n, q.x * n, q.y * n, q.z * n};
+}
+
+// tracker of rank `rank` of the frame whose tracked-joint mask is `tmask` (E of them): inputs from global memory, rotated
+// into the frame of `cur`, stored in the frame block (general path, epilogue) and returned
+DEV TRec make_tracker(const KArgs& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur)
 {
-    const bool trk = optimise && id.is_joint && item < NJ && ((tmask >> item) & 1u);
-    const int rank = __popc(tmask & ((1u << (item & 31)) - 1u));
-    const int E = __popc(tmask);
-    unsigned sel6 = 0, m = tmask;
-    for (int u = 0; u < 6; ++u) {
-        const int t = __builtin_ctz(m | 0x80000000u);
-        m &= m - 1u;
-        sel6 |= ((id.ch_sub >> t) & 1u) << u;
-    }
-    if (item == 0) {
-        *(f4*)(fr.qd + 20) = *(const f4*)(a.cur_rot + (size_t)gf * 4);
-        fr.qd[24] = __uint_as_float(tmask);
-    }
-    if (trk) {
+    TRec t;
+    t.act = rank < E;
+    t.rank = rank;
+    unsigned m = tmask;
+    for (int u = 0; u < rank; ++u) m &= m - 1u;
+    const int j = t.act ? __builtin_ctz(m | 0x80000000u) : 0;
+    t.qs = FB_QS + 4 * (j == 0 ? QS_IDENT : j); // the root is the identity in its own frame
+    t.wt = FB_WT + 4 * (j == 0 ? WT_TRASH : j); // ... and has no torque of its own: everything goes to the root sum
+    t.plo = a.items[j].path_lo;
+    t.phi = a.items[j].path_hi;
+    t.tp = {0.f, 0.f, 0.f};
+    t.qT = {1.f, 0.f, 0.f, 0.f};
+    t.cgp = t.clp = t.k8 = t.clr8 = 0.f;
+    if (t.act) {
         const float invE = 1.f / (float)E;
-        const float* p = a.tgt_pos + (size_t)(gf * NJ + item) * 3;
-        const float* q = a.tgt_rot + (size_t)(gf * NJ + item) * 9;
-        const float wp = a.w[(gf * NJ + item) * 2 + 0], wr = a.w[(gf * NJ + item) * 2 + 1];
-        const float clp = wp * invE * (1.f / 3.f);             // loss_pos coefficient  w_pos / (3E)
+        const float* p = a.tgt_pos + (size_t)(gf * NJ + j) * 3;
+        const float wp = a.w[(gf * NJ + j) * 2 + 0], wr = a.w[(gf * NJ + j) * 2 + 1];
+        t.tp = rot_conj(cur, V3{p[0], p[1], p[2]});
+        t.qT = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, quat_from_rotmat(a.tgt_rot + (size_t)(gf * NJ + j) * 9));
+        t.clp = wp * invE * (1.f / 3.f);                       // loss_pos coefficient  w_pos / (3E)
         const float clr = a.lam_rot * wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
-        float* t = fr.trk + rank * 4;
-        *(f4*)(t) = f4{p[0], p[1], p[2], 2.f * clp};
-        *(f4*)(t + 4 * R) = f4{q[0], q[1], q[2], q[3]};
-        *(f4*)(t + 8 * R) = f4{q[4], q[5], q[6], q[7]};
-        *(f4*)(t + 12 * R) = f4{q[8], 2.f * clr, clp, clr};
+        t.cgp = 2.f * t.clp;
+        t.k8 = -8.f * clr;
+        t.clr8 = 8.f * clr;
+        float* ti = fb + FB_TI + rank * 4;
+        *(f4*)(ti) = f4{t.tp.x, t.tp.y, t.tp.z, t.cgp};
+        *(f4*)(ti + 4 * W4_R) = f4{t.qT.w, t.qT.x, t.qT.y, t.qT.z};
+        *(f4*)(ti + 8 * W4_R) = f4{t.k8, t.clp, t.clr8, __int_as_float(j)};
     }
-    // constant root-frame bones of the root's children
-    if (item < MAX_ROOT_CH) *(f4*)(fr.bone + icg->init_id * 4) = f4{icg->init_off[0], icg->init_off[1], icg->init_off[2], 0.f};
-    return (trk ? 1u : 0u) | ((unsigned)(rank & 31) << 1) | (sel6 << 8);
+    return t;
 }
 
-// stage 1: normalise, rotation matrix, child bone; root / displacement publish qw, R0, d
-template <int R>
-DEV void w4_s1(const KArgs& a, const ItemId& id, unsigned pk, const float* icl, const f4 y4, const FrameRows<R>& fr, P3S& s, int iter,
-               int gf, bool fvalid)
-{
-    const bool trk = (pk & 1u) != 0u;
-    const int rank = (int)((pk >> 1) & 31u);
-    const float* tin = fr.trk + rank * 4;
-    s.cv = *(const f4*)(fr.qd + 20); // cur_rot of my frame: used by the root lane only
-    if (DBG_DUMP && a.dbg && iter == 0 && fvalid && id.dq == id.sq) *(f4*)(a.dbg + (size_t)gf * DBG_STRIDE + DBG_Y + 4 * id.sq) = y4;
-    const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
-    s.sd = sd;
-    const Q4 rq = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
-    const float nn = rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z;
-    const float inv = id.has_quat ? __builtin_amdgcn_rsqf(nn) : 0.f;
-    s.inv = inv;
-    const Q4 q = {rq.w * inv, rq.x * inv, rq.y * inv, rq.z * inv};
-    s.q = q;
-    // one quaternion -> matrix for every lane: the root lane's is the world rotation qw = cur (x) q_0 (its own M is
-    // the identity in the root frame), every other lane's is its root-space joint rotation (1 (x) q = q exactly)
-    const Q4 qs = quat_mul(id.is_root ? Q4{s.cv.x, s.cv.y, s.cv.z, s.cv.w} : Q4{1.f, 0.f, 0.f, 0.f}, q);
-    M3 M = quat_to_mat(qs);
-    if (id.is_root) {
-        *(f4*)(fr.qd) = f4{qs.w, qs.x, qs.y, qs.z};
-        *(f4*)(fr.qd + 8) = f4{M.m00, M.m01, M.m02, 0.f};
-        *(f4*)(fr.qd + 12) = f4{M.m10, M.m11, M.m12, 0.f};
-        *(f4*)(fr.qd + 16) = f4{M.m20, M.m21, M.m22, 0.f};
-    }
-    if (id.is_root) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-    if (id.is_disp) *(f4*)(fr.qd + 4) = f4{rq.w, rq.x, rq.y, 0.f};
-    s.M = M;
-    {
-        const f4 cho = *(const f4*)(icl + 256); // child offset (x,y,z)
-        const V3 u = mat_vec(M, V3{cho.x, cho.y, cho.z});
-        *(f4*)(fr.bone + id.ch_id * 4) = f4{u.x, u.y, u.z, 0.f};
-    }
-    if (trk) { // tracker inputs of my joint (loop-invariant LDS data)
-        s.t0 = *(const f4*)(tin);          // tp, cgp
-        s.t1 = *(const f4*)(tin + 4 * R);  // tR[0..3]
-        s.t2 = *(const f4*)(tin + 8 * R);  // tR[4..7]
-        s.t3 = *(const f4*)(tin + 12 * R); // tR[8], cgr, clp, clr
-    }
+DEV TRec load_tracker(const KArgs& a, const float* fb, int E, int rank)
+{ // the same from the frame block (ranks beyond the first 16 of a frame: rare)
+    TRec t;
+    t.act = rank < E;
+    t.rank = rank;
+    const float* ti = fb + FB_TI + (t.act ? rank : 0) * 4;
+    const f4 i0 = *(const f4*)(ti), i1 = *(const f4*)(ti + 4 * W4_R), i2 = *(const f4*)(ti + 8 * W4_R);
+    const int j = t.act ? __float_as_int(i2.w) : 0;
+    t.qs = FB_QS + 4 * (j == 0 ? QS_IDENT : j);
+    t.wt = FB_WT + 4 * (j == 0 ? WT_TRASH : j);
+    t.plo = a.items[j].path_lo;
+    t.phi = a.items[j].path_hi;
+    t.tp = {i0.x, i0.y, i0.z};
+    t.cgp = i0.w;
+    t.qT = {i1.x, i1.y, i1.z, i1.w};
+    t.k8 = i2.x; t.clp = i2.y; t.clr8 = i2.z;
+    return t;
 }
 
-// stage 2: root-frame position, tracker terms
-template <int R> DEV void w4_s2(const ItemId& id, unsigned pk, const FrameRows<R>& fr, P3S& s)
+DEV int path_len(unsigned plo, unsigned phi)
 {
-    const bool trk = (pk & 1u) != 0u;
-    const int rank = (int)((pk >> 1) & 31u);
-    const f4 qwv = *(const f4*)(fr.qd);
-    const f4 dv = *(const f4*)(fr.qd + 4);
-    const f4 r0v = *(const f4*)(fr.qd + 8), r1v = *(const f4*)(fr.qd + 12), r2v = *(const f4*)(fr.qd + 16);
-    const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
-    const M3 R0 = {r0v.x, r0v.y, r0v.z, r1v.x, r1v.y, r1v.z, r2v.x, r2v.y, r2v.z};
-    const M3& M = s.M;
-    V3 pr = {dv.x, dv.y, dv.z}; // root-frame position: d + sum of the bones on the path
-    {
-        f4 bn[MAX_PATH];
+    int n = 0;
+    for (int k = 0; k < MAX_PATH; ++k) n += (((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)) != (unsigned)SLOT_ZERO) ? 1 : 0;
+    return n;
+}
+
+// ---- stage J: both items of my quad, packed
+struct JOut { f2 q[4], u[3], inv; };
+DEV void j_stage(const PairC& c, float* fb, const f4 yA, const f4 yB, JOut& o)
+{
+    f2 rq[4];
 #pragma unroll
-        for (int i = 0; i < MAX_PATH; ++i) {
-            const unsigned k = (i < 6) ? ((id.plo >> (5 * i)) & 31u) : (id.phi & 31u);
-            bn[i] = *(const f4*)(fr.bone + k * 4);
+    for (int k = 0; k < 4; ++k) rq[k] = f2{yA[k], yB[k]} * c.sd[k] + c.mu[k];
+    const f2 nn = rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3];
+    const float invA = __builtin_amdgcn_rsqf(nn.x);
+    const float invB = c.kindB == KIND_DISP ? 1.f : (c.kindB == KIND_IDLE ? 0.f : __builtin_amdgcn_rsqf(nn.y));
+    o.inv = f2{invA, invB};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.q[k] = rq[k] * o.inv; // (the displacement item passes its de-normalised channels through)
+    // child bone u = R(q) off = off + 2 (w t + v x t), t = v x off
+    const f2 w = o.q[0], vx = o.q[1], vy = o.q[2], vz = o.q[3];
+    const f2 tx = vy * c.off[2] - vz * c.off[1], ty = vz * c.off[0] - vx * c.off[2], tz = vx * c.off[1] - vy * c.off[0];
+    const f2 cx = vy * tz - vz * ty, cy = vz * tx - vx * tz, cz = vx * ty - vy * tx;
+    o.u[0] = c.off[0] + 2.f * (w * tx + cx);
+    o.u[1] = c.off[1] + 2.f * (w * ty + cy);
+    o.u[2] = c.off[2] + 2.f * (w * tz + cz);
+    float* qa = fb + c.qsA; float* qb = fb + c.qsB; float* ba = fb + c.bnA; float* bb = fb + c.bnB;
+    qa[0] = o.q[0].x; qa[1] = o.q[1].x; qa[2] = o.q[2].x; qa[3] = o.q[3].x;
+    qb[0] = o.q[0].y; qb[1] = o.q[1].y; qb[2] = o.q[2].y; qb[3] = o.q[3].y;
+    ba[0] = o.u[0].x; ba[1] = o.u[1].x; ba[2] = o.u[2].x;
+    bb[0] = o.u[0].y; bb[1] = o.u[1].y; bb[2] = o.u[2].y;
+}
+
+// ---- stage T: one tracker per lane
+DEV void t_stage(const TRec& t, float* fb, int Lmax, bool losses)
+{
+    if (!t.act) return;
+    const f4 q0v = *(const f4*)(fb + FB_QS), qtv = *(const f4*)(fb + t.qs), dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
+    V3 p = {dv.x, dv.y, dv.z}; // root-frame position: displacement + the bones on the path
+#pragma unroll
+    for (int k = 0; k < MAX_PATH; ++k) {
+        if (k < Lmax) { // (uniform)
+            const unsigned s = (k < 6) ? ((t.plo >> (5 * k)) & 31u) : (t.phi & 31u);
+            const f4 bn = *(const f4*)(fb + FB_BN + 4 * s);
+            p.x += bn.x; p.y += bn.y; p.z += bn.z;
         }
-#pragma unroll
-        for (int i = 0; i < MAX_PATH; ++i) { pr.x += bn[i].x; pr.y += bn[i].y; pr.z += bn[i].z; }
     }
-    M3 gM = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (trk) { // tracker terms in the root frame
-        const f4 t0 = s.t0, t1 = s.t1, t2 = s.t2, t3 = s.t3;
-        const V3 tp = {t0.x, t0.y, t0.z};
-        const M3 tR = {t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x};
-        const float cgp = t0.w, cgr = t3.y;
-        const V3 tpr = matT_vec(R0, tp);
-        const V3 e = {pr.x - tpr.x, pr.y - tpr.y, pr.z - tpr.z};
-        const V3 gp = {cgp * e.x, cgp * e.y, cgp * e.z};
-        const M3 tRr = matT_mat(R0, tR);
-        const M3 eM = {M.m00 - tRr.m00, M.m01 - tRr.m01, M.m02 - tRr.m02, M.m10 - tRr.m10, M.m11 - tRr.m11,
-                       M.m12 - tRr.m12, M.m20 - tRr.m20, M.m21 - tRr.m21, M.m22 - tRr.m22};
-        gM = {cgr * eM.m00, cgr * eM.m01, cgr * eM.m02, cgr * eM.m10, cgr * eM.m11, cgr * eM.m12,
-              cgr * eM.m20, cgr * eM.m21, cgr * eM.m22};
-        // dL/dR0 = -(tp gp^T + tR gM^T)  ->  contribution to dL/d(qw)
-        M3 C = mat_matT(tR, gM);
-        C.m00 = -(C.m00 + tp.x * gp.x); C.m01 = -(C.m01 + tp.x * gp.y); C.m02 = -(C.m02 + tp.x * gp.z);
-        C.m10 = -(C.m10 + tp.y * gp.x); C.m11 = -(C.m11 + tp.y * gp.y); C.m12 = -(C.m12 + tp.y * gp.z);
-        C.m20 = -(C.m20 + tp.z * gp.x); C.m21 = -(C.m21 + tp.z * gp.y); C.m22 = -(C.m22 + tp.z * gp.z);
-        const Q4 gqw_t = quat_mat_grad(qw, C);
-        *(f4*)(fr.gpc + rank * 4) = f4{gp.x, gp.y, gp.z, 0.f};
-        *(f4*)(fr.cq + rank * 4) = f4{gqw_t.w, gqw_t.x, gqw_t.y, gqw_t.z};
-        const float l_p = t3.z * (e.x * e.x + e.y * e.y + e.z * e.z);
-        const float l_r = t3.w * (eM.m00 * eM.m00 + eM.m01 * eM.m01 + eM.m02 * eM.m02 + eM.m10 * eM.m10 + eM.m11 * eM.m11 +
-                                  eM.m12 * eM.m12 + eM.m20 * eM.m20 + eM.m21 * eM.m21 + eM.m22 * eM.m22);
-        *(f2*)(fr.lp + rank * 2) = f2{l_p, l_r}; // read by the epilogue after the last iteration
-    }
-    s.gM = gM;
+    const Q4 q0 = {q0v.x, q0v.y, q0v.z, q0v.w};
+    const V3 at = rot_conj(q0, t.tp); // target position in the root frame
+    const V3 e = {p.x - at.x, p.y - at.y, p.z - at.z};
+    const V3 gp = {t.cgp * e.x, t.cgp * e.y, t.cgp * e.z};
+    // rotation error  s = conj(q0) (x) qT (x) conj(qt):  scalar part c = <q0 (x) qt, qT>,  |M - T|_F^2 = 8 |vec s|^2
+    const Q4 r = quat_mul(Q4{q0.w, -q0.x, -q0.y, -q0.z}, t.qT);
+    const Q4 s = quat_mul(r, Q4{qtv.x, -qtv.y, -qtv.z, -qtv.w});
+    const float k = t.k8 * s.w;
+    const V3 own = {k * s.x, k * s.y, k * s.z}; // torque on the tracked joint (and on the root)
+    const V3 ag = cross(at, gp);
+    *(f4*)(fb + FB_GP + 4 * t.rank) = f4{gp.x, gp.y, gp.z, 0.f};
+    *(f4*)(fb + FB_RT + 4 * t.rank) = f4{ag.x + own.x, ag.y + own.y, ag.z + own.z, 0.f};
+    *(f4*)(fb + t.wt) = f4{own.x, own.y, own.z, 0.f};
+    if (losses) // (uniform) read by the epilogue
+        *(f2*)(fb + FB_LP + 2 * t.rank) = f2{t.clp * (e.x * e.x + e.y * e.y + e.z * e.z), t.clr8 * (s.x * s.x + s.y * s.y + s.z * s.z)};
 }
 
-// stage 3: subtree sums, dL/dq, projection -> the item's quad of dL/dy
-template <int R>
-DEV f4 w4_s3(const KArgs& a, const ItemId& id, unsigned pk, int Emax, const float* icl, const FrameRows<R>& fr, const P3S& s, int iter,
-             int gf, bool fvalid)
+// ---- stage G: both items of my quad, packed -> their quads of dL/dy
+DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask, int Emax, f4& gyA, f4& gyB)
 {
-    f4 S4 = {0.f, 0.f, 0.f, 0.f};
+    f2 S[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
     {
-        const float* tab = id.is_root ? fr.cq : fr.gpc;
+        const float* tab = fb + c.tab;
         f4 g[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(tab + u * 4);
-        const unsigned sel6 = pk >> 8;
+        for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(tab + 4 * u);
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const float bb = (float)((sel6 >> u) & 1u);
-            S4.x += bb * g[u].x; S4.y += bb * g[u].y; S4.z += bb * g[u].z; S4.w += bb * g[u].w;
-        }
+        for (int u = 0; u < 6; ++u) { S[0] += c.sel[u] * splat2(g[u].x); S[1] += c.sel[u] * splat2(g[u].y); S[2] += c.sel[u] * splat2(g[u].z); }
         if (Emax > 6) { // more than 6 trackers in a frame of this wave (uniform, rare): general path
-            unsigned m = __float_as_uint(fr.qd[24]);
+            unsigned m = tmask;
 #pragma unroll
             for (int u = 0; u < 6; ++u) m &= m - 1u;
             for (int e0 = 6; e0 < Emax; ++e0) {
-                const f4 ge = *(const f4*)(tab + e0 * 4);
+                const f4 ge = *(const f4*)(tab + 4 * e0);
                 const int t = __builtin_ctz(m | 0x80000000u); // joint id of this rank (31 when exhausted)
                 m &= m - 1u;
-                const float bb = (float)((id.ch_sub >> t) & 1u);
-                S4.x += bb * ge.x; S4.y += bb * ge.y; S4.z += bb * ge.z; S4.w += bb * ge.w;
+                const f2 sl = f2{(float)((c.subA >> t) & 1u), (float)((c.subB >> t) & 1u)};
+                S[0] += sl * splat2(ge.x); S[1] += sl * splat2(ge.y); S[2] += sl * splat2(ge.z);
             }
         }
     }
-    const Q4 q = s.q;
-    const f4 sd = s.sd, cv = s.cv;
-    const float inv = s.inv;
-    const Q4 gq_root = quat_mul(Q4{cv.x, -cv.y, -cv.z, -cv.w}, Q4{S4.x, S4.y, S4.z, S4.w});
-    const f4 cho = *(const f4*)(icl + 256);
-    M3 X = s.gM;
-    X.m00 += S4.x * cho.x; X.m01 += S4.x * cho.y; X.m02 += S4.x * cho.z;
-    X.m10 += S4.y * cho.x; X.m11 += S4.y * cho.y; X.m12 += S4.y * cho.z;
-    X.m20 += S4.z * cho.x; X.m21 += S4.z * cho.y; X.m22 += S4.z * cho.z;
-    const Q4 gq_joint = quat_mat_grad(q, X);
-    const Q4 gq = id.is_root ? gq_root : gq_joint;
-    const V3 S = {S4.x, S4.y, S4.z};
-    const float dot = q.w * gq.w + q.x * gq.x + q.y * gq.y + q.z * gq.z;
-    f4 gyv = {sd.x * (gq.w - q.w * dot) * inv, sd.y * (gq.x - q.x * dot) * inv,
-              sd.z * (gq.y - q.y * dot) * inv, sd.w * (gq.z - q.z * dot) * inv};
-    if (id.is_disp) gyv = f4{sd.x * S.x, sd.y * S.y, sd.z * S.z, 0.f}; // ch_sub = every joint
-    if (id.dq < 0) gyv = f4{0.f, 0.f, 0.f, 0.f};
-    if (DBG_DUMP && a.dbg && iter == 0 && fvalid && id.dq >= 0) *(f4*)(a.dbg + (size_t)gf * DBG_STRIDE + DBG_GY + 4 * id.dq) = gyv;
-    return gyv;
+    const f4 wa = *(const f4*)(fb + c.wtA), wb = *(const f4*)(fb + c.wtB);
+    // torque: bone x S (+ own rotation torque); on the root the sum over the trackers' root torques itself
+    f2 t0 = j.u[1] * S[2] - j.u[2] * S[1] + c.rho * S[0];
+    f2 t1 = j.u[2] * S[0] - j.u[0] * S[2] + c.rho * S[1];
+    f2 t2 = j.u[0] * S[1] - j.u[1] * S[0] + c.rho * S[2];
+    t0 += f2{wa.x, wb.x}; t1 += f2{wa.y, wb.y}; t2 += f2{wa.z, wb.z};
+    // dL/dq = (0, a) (x) q = (-a.v, w a + a x v), a = 2 tau   (root: q (x) (0, a): the cross product changes sign)
+    const f2 a0 = t0 + t0, a1 = t1 + t1, a2 = t2 + t2;
+    const f2 w = j.q[0], vx = j.q[1], vy = j.q[2], vz = j.q[3];
+    const f2 g0 = -(a0 * vx + a1 * vy + a2 * vz);
+    const f2 g1 = w * a0 + c.sgn * (a1 * vz - a2 * vy);
+    const f2 g2 = w * a1 + c.sgn * (a2 * vx - a0 * vz);
+    const f2 g3 = w * a2 + c.sgn * (a0 * vy - a1 * vx);
+    // through the normalisation (already tangent: no projection) and the de-normalisation
+    const f2 si = j.inv;
+    f2 y0 = c.sd[0] * (g0 * si), y1 = c.sd[1] * (g1 * si), y2 = c.sd[2] * (g2 * si), y3 = c.sd[3] * (g3 * si);
+    if (c.kindB == KIND_DISP) { y0.y = c.sd[0].y * S[0].y; y1.y = c.sd[1].y * S[1].y; y2.y = c.sd[2].y * S[2].y; y3.y = 0.f; }
+    gyA = f4{y0.x, y1.x, y2.x, y3.x};
+    gyB = f4{y0.y, y1.y, y2.y, y3.y};
 }
 
-// outputs of the LAST forward pass of (item, frame gf): the same as dp_p3.h::p3_outputs with the decoder quad in registers
-template <int R>
-DEV void w4_outputs(const KArgs& a, const ItemId& id, const float* icl, const f4 y4, const FrameRows<R>& fr, int item, int gf, bool optimise,
-                    const float* zpre_row, const float* zt_row)
+// ---- outputs of the LAST forward pass of (item, frame gf) from its decoder quad and the frame block (reference:
+// drag_pose.py:84-113 and what run() returns); kept simple, it runs once
+DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const f4 y4, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask)
 {
-    const f4 sd = *(const f4*)(icl), mu = *(const f4*)(icl + 128);
+    const int item = pp->item[side], kind = pp->kind[side];
+    if (item < 0 || kind == KIND_IDLE || kind == KIND_VIRT) return;
+    const f4 sd = {pp->sd[0][side], pp->sd[1][side], pp->sd[2][side], pp->sd[3][side]};
+    const f4 mu = {pp->mu[0][side], pp->mu[1][side], pp->mu[2][side], pp->mu[3][side]};
     const Q4 rq = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
-    const float inv = id.has_quat ? __builtin_amdgcn_rsqf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z) : 0.f;
-    const Q4 q = {rq.w * inv, rq.x * inv, rq.y * inv, rq.z * inv};
-    M3 M = quat_to_mat(q);
-    if (id.is_root) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-    const f4 qwv = *(const f4*)(fr.qd);
-    const f4 dv = *(const f4*)(fr.qd + 4);
-    const Q4 qw = {qwv.x, qwv.y, qwv.z, qwv.w};
+    const f4 q0v = *(const f4*)(fb + FB_QS);
+    const Q4 qw = quat_mul(cur, Q4{q0v.x, q0v.y, q0v.z, q0v.w}); // world rotation (drag_pose.py:88)
     const M3 R0 = quat_to_mat(qw);
-    if (id.is_joint) {
-        if (a.pose) {
-            float* o = a.pose + (size_t)gf * 88 + 4 * item;
-            o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y;
-            o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+    if (kind == KIND_DISP) {
+        if (a.disp) { float* o = a.disp + (size_t)gf * 3; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; }
+        if (a.world_disp) {
+            const V3 wd = mat_vec(R0, V3{rq.w, rq.x, rq.y});
+            float* o = a.world_disp + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
         }
-        if (a.pos) {
-            V3 pr = {dv.x, dv.y, dv.z};
-            for (int i = 0; i < MAX_PATH; ++i) {
-                const unsigned k = (i < 6) ? ((id.plo >> (5 * i)) & 31u) : (id.phi & 31u);
-                const f4 bn = *(const f4*)(fr.bone + k * 4);
-                pr.x += bn.x; pr.y += bn.y; pr.z += bn.z;
-            }
-            const V3 pw = mat_vec(R0, pr);
-            float* o = a.pos + ((size_t)gf * NJ + item) * 3;
-            o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
-        }
-        if (a.rot) {
-            const M3 G = mat_mat(R0, M);
-            float* o = a.rot + ((size_t)gf * NJ + item) * 9;
-            o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
-        }
+        return;
     }
-    if (id.is_root) {
+    const float inv = __builtin_amdgcn_rsqf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);
+    const Q4 q = {rq.w * inv, rq.x * inv, rq.y * inv, rq.z * inv};
+    if (a.pose) {
+        float* o = a.pose + (size_t)gf * 88 + 4 * item;
+        o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y; o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+    }
+    if (a.pos) {
+        const f4 dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
+        V3 pr = {dv.x, dv.y, dv.z};
+        const unsigned plo = a.items[item].path_lo, phi = a.items[item].path_hi;
+        for (int k = 0; k < MAX_PATH; ++k) {
+            const unsigned s = (k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u);
+            const f4 bn = *(const f4*)(fb + FB_BN + 4 * s);
+            pr.x += bn.x; pr.y += bn.y; pr.z += bn.z;
+        }
+        const V3 pw = mat_vec(R0, pr);
+        float* o = a.pos + ((size_t)gf * NJ + item) * 3;
+        o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+    }
+    if (a.rot) {
+        M3 M = quat_to_mat(q);
+        if (kind == KIND_ROOT) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        const M3 G = mat_mat(R0, M);
+        float* o = a.rot + ((size_t)gf * NJ + item) * 9;
+        o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
+    }
+    if (kind == KIND_ROOT) {
         if (a.world_rot) { float* o = a.world_rot + (size_t)gf * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
         if (optimise && a.loss) {
             float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
-            const int E = __popc(__float_as_uint(fr.qd[24]));
-            for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(fr.lp + e0 * 2); lsum_p += l.x; lsum_r += l.y; }
+            const int E = min(__popc(tmask), W4_R);
+            for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(fb + FB_LP + 2 * e0); lsum_p += l.x; lsum_r += l.y; }
             for (int k = 0; k < LAT; k += 4) {
-                const f4 dz = *(const f4*)(zpre_row + k) - *(const f4*)(zt_row + k);
+                const f4 dz = *(const f4*)(fb + FB_ZPRE + k) - *(const f4*)(fb + FB_ZT + k);
                 lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
             }
             a.loss[(size_t)gf * 3 + 0] = lsum_p;
             a.loss[(size_t)gf * 3 + 1] = lsum_r;
             a.loss[(size_t)gf * 3 + 2] = lt * a.lam_tmp * (1.f / 24.f);
-        }
-    }
-    if (id.is_disp) {
-        if (a.disp) { float* o = a.disp + (size_t)gf * 3; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; }
-        if (a.world_disp) {
-            const V3 wd = mat_vec(R0, V3{rq.w, rq.x, rq.y});
-            float* o = a.world_disp + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
         }
     }
 }
@@ -357,18 +417,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = lane >> 2, i = lane & 3; // quad = item (block of the products), lane in quad = frame
+    const int b = lane >> 2, i = lane & 3; // quad (item pair / block of the products / tracker rank), lane in quad = frame
     const int nB = a.n_frames;
     const int f0 = (blockIdx.x * NW + wave) * FPW;
     const bool optimise = (a.mode == 0);
 
-    // ---- weight image and item tables into LDS (the only data the waves of a workgroup share)
-    for (int k = tid; k < IMG_FLOATS / 4; k += NW * 64) ((f4*)(lds + L_IMG))[k] = ((const f4*)a.w4img)[k];
-    if (tid < 32 * 3) {
-        const int it = tid & 31, k = tid >> 5;
-        const float* src = (const float*)(a.items + it) + (k == 0 ? 0 : k == 1 ? 4 : 8);
-        *(f4*)(lds + L_ITEM + k * 128 + 4 * it) = f4{src[0], src[1], src[2], k == 2 ? 0.f : src[3]};
-    }
+    // ---- streamed weight images into LDS (the only data the waves of a workgroup share); frame blocks zeroed
+    for (int k = tid; k < NG_B2 * 64; k += NW * 64) ((f4*)(lds + L_IMG2))[k] = ((const f4*)a.w4img)[GR_B2 * 64 + k];
+    for (int k = tid; k < NG_B0 * 64; k += NW * 64) ((f4*)(lds + L_IMG0))[k] = ((const f4*)a.w4img)[GR_B0 * 64 + k];
     float* fb0 = lds + L_FR + wave * FPW * FB_STRIDE; // this wave's four frame blocks
     for (int k = lane; k < FPW * FB_STRIDE; k += 64) fb0[k] = 0.f;
     __syncthreads();
@@ -377,7 +433,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const int gfi = min(f0 + i, nB - 1); // my frame as the lane of a quad (clamped: ragged tails compute a copy)
     const bool fvalid = f0 + i < nB;
     float* fb = fb0 + i * FB_STRIDE;
-    const FrameRows<W4_R> fr = {fb + FB_BONE, fb + FB_GPC, fb + FB_CQ, fb + FB_LP, fb + FB_QD, fb + FB_TRK};
 
     // ---- per-lane accumulator seeds (bias rows of L0, L1, L2A, L2B)
     const float bias0 = a.w4bias[lane], bias1 = a.w4bias[64 + lane], bias2a = a.w4bias[128 + lane], bias2b = a.w4bias[192 + lane];
@@ -393,82 +448,184 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         }
     }
 
-    // ---- kinematics identity of my two items
-    const int itA = b, itB = ITEMS_A + b;
-    const ItemId idA = load_item(a.items + itA), idB = load_item(a.items + itB);
-    const float* iclA = lds + L_ITEM + 4 * itA;
-    const float* iclB = lds + L_ITEM + 4 * itB;
+    // ---- kinematics constants of my quad's two items
+    const Pair* pp = a.w4pairs + b;
+    PairC pc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pc.sd[k] = f2{pp->sd[k][0], pp->sd[k][1]}; pc.mu[k] = f2{pp->mu[k][0], pp->mu[k][1]}; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pc.off[k] = f2{pp->off[k][0], pp->off[k][1]};
+    pc.sgn = f2{pp->sgn[0], pp->sgn[1]};
+    pc.rho = f2{pp->rho[0], pp->rho[1]};
+    pc.subA = pp->ch_sub[0]; pc.subB = pp->ch_sub[1];
+    pc.itemA = pp->item[0]; pc.itemB = pp->item[1];
+    pc.kindB = pp->kind[1];
+    pc.qsA = FB_QS + 4 * pc.itemA;
+    pc.qsB = FB_QS + 4 * (pc.itemB >= 0 ? pc.itemB : QS_TRASH);
+    pc.bnA = FB_BN + 4 * pp->bone_slot[0];
+    pc.bnB = FB_BN + 4 * pp->bone_slot[1];
+    pc.wtA = FB_WT + 4 * (pp->kind[0] == KIND_JOINT ? pc.itemA : WT_ZERO);               // the root takes its torque from the root sum,
+    pc.wtB = FB_WT + 4 * (pc.kindB == KIND_JOINT && pc.itemB >= 0 ? pc.itemB : WT_ZERO); // virtual copies only carry a bone
+    pc.tab = pp->kind[0] == KIND_ROOT ? FB_RT : FB_GP;
+
+    // ---- trackers of my frame
     unsigned tmask = 0;
     if (optimise)
         for (int j = 0; j < NJ; ++j) tmask |= (a.tracked[(size_t)gfi * NJ + j] != 0 ? 1u : 0u) << j;
-    const unsigned pkA = w4_setup<W4_R>(a, a.items + itA, idA, itA, tmask, gfi, optimise, fr);
-    const unsigned pkB = w4_setup<W4_R>(a, a.items + itB, idB, itB, tmask, gfi, optimise, fr);
-    const int E = __popc(tmask);
+    const int E = min(__popc(tmask), W4_R);
     const int Emax = max(max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 1)),
                          max(__builtin_amdgcn_readlane(E, 2), __builtin_amdgcn_readlane(E, 3)));
+    {
+        unsigned m = tmask;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) { // first 6 ranks: the fast path of stage G
+            const int t = __builtin_ctz(m | 0x80000000u);
+            pc.sel[u] = (u < E) ? f2{(float)((pc.subA >> t) & 1u), (float)((pc.subB >> t) & 1u)} : splat2(0.f);
+            m &= m - 1u;
+        }
+    }
+    Q4 cur = {1.f, 0.f, 0.f, 0.f};
+    {
+        const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
+        cur = {cv.x, cv.y, cv.z, cv.w};
+    }
+    const TRec trk = make_tracker(a, fb, gfi, tmask, E, b, cur); // lane 4u+i: tracker of rank u of frame i
+    for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur);
+    int Lmax = 0;
+    for (int base = 0; base < Emax; base += 16) {
+        const TRec t = base == 0 ? trk : load_tracker(a, fb, E, base + b);
+        const int len = t.act ? path_len(t.plo, t.phi) : 0;
+        for (int k = 1; k <= MAX_PATH; ++k)
+            if (__ballot(len >= k) != 0ull) Lmax = max(Lmax, k);
+    }
+    if (b == 0) *(f4*)(fb + FB_QS + 4 * QS_IDENT) = f4{1.f, 0.f, 0.f, 0.f};
+    if (b < MAX_ROOT_CH) { // constant root-frame bones of the root's children
+        const ItemConst* ic = a.items + b;
+        *(f4*)(fb + FB_BN + 4 * ic->init_id) = f4{ic->init_off[0], ic->init_off[1], ic->init_off[2], 0.f};
+    }
+
+    // ---- resident weight images (MFMA B operands, loop-invariant, accumulator registers): L0, L1, L2A, L2B, bL1 =
+    //      61 groups = 244 registers, straight from the (L2-resident) global image
+    f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15];
+    {
+        const f4* w = (const f4*)a.w4img + lane;
+        load_w<6>(wL0, w + (S_L0 / 4) * 64);
+        load_w<10>(wL1, w + (S_L1 / 4) * 64);
+        load_w<15>(wL2A, w + (S_L2A / 4) * 64);
+        load_w<15>(wL2B, w + (S_L2B / 4) * 64);
+        load_w<15>(wB1, w + (S_B1 / 4) * 64);
+    }
     wave_sync();
 
     f4 yA = {0.f, 0.f, 0.f, 0.f}, yB = yA;
-    P3S sA, sB;
+    JOut jo;
+    Prof prof;
+    prof.start();
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
         const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
         int o = lane;
-        asm volatile("" : "+v"(o)); // opaque per iteration: keeps the weight reads inside the loop (nothing to hoist and spill)
-        const f4* w = (const f4*)(lds + L_IMG) + o;
+        asm volatile("" : "+v"(o)); // opaque per iteration: keeps the streamed weight reads inside the loop
+        const f4* w2 = (const f4*)(lds + L_IMG2) + o;
+        const f4* w0 = (const f4*)(lds + L_IMG0) + o;
 
         // ================= L0: a0 = lrelu(A0 z + c0)
         f4 x = zD;
         quad_transpose(x);
         f4 acc0 = splat(bias0), acc1 = splat(0.f);
-        chain<6, 0>(acc0, acc1, x, w + (S_L0 / 4) * 64);
+        chain_begin();
+        chain_a<6, 0>(acc0, acc1, x, wL0);
+        chain_end(acc0, acc1);
         const f4 a0D = lrelu4(acc0 + acc1);
+        STAMP(0);
         // ================= L1: a1 = lrelu(A1 a0 + b1)
         x = a0D;
         quad_transpose(x);
         acc0 = splat(bias1); acc1 = splat(0.f);
-        chain<10, 0>(acc0, acc1, x, w + (S_L1 / 4) * 64);
+        chain_begin();
+        chain_a<10, 0>(acc0, acc1, x, wL1);
+        chain_end(acc0, acc1);
         const f4 a1D = lrelu4(acc0 + acc1);
-        // ================= L2: y = A2 a1 + b2, two 64-row blocks (items 0..15 | 16..31)
+        STAMP(1);
+        // ================= L2: y = A2 a1 + b2, two 64-row blocks (side A | side B items)
         x = a1D;
         quad_transpose(x);
         {
             f4 pa0 = splat(bias2a), pa1 = splat(0.f), pb0 = splat(bias2b), pb1 = splat(0.f);
-            chain<15, 0>(pa0, pa1, x, w + (S_L2A / 4) * 64);
-            chain<15, 0>(pb0, pb1, x, w + (S_L2B / 4) * 64);
+            chain_begin();
+            chain_a<15, 0>(pa0, pa1, x, wL2A);
+            chain_a<15, 0>(pb0, pb1, x, wL2B);
+            chain_end(pa0, pa1);
             yA = pa0 + pa1;
             yB = pb0 + pb1;
         }
-        quad_transpose(yA); // lane (b, i): the decoder quad of item b / 16 + b of frame i
+        quad_transpose(yA); // lane (b, i): the decoder quads of my two items of frame i
         quad_transpose(yB);
+        STAMP(2);
 
-        // ================= P3: normalise, FK, loss, backward to dL/dy
-        w4_s1<W4_R>(a, idA, pkA, iclA, yA, fr, sA, iter, gfi, fvalid);
-        w4_s1<W4_R>(a, idB, pkB, iclB, yB, fr, sB, iter, gfi, fvalid);
+        // ================= kinematics
+        if (DBG_DUMP && a.dbg && iter == 0 && fvalid) {
+            if (pc.itemA >= 0) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_Y + 4 * pc.itemA) = yA;
+            if (pc.itemB >= 0 && pc.kindB != KIND_VIRT) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_Y + 4 * pc.itemB) = yB;
+        }
+        j_stage(pc, fb, yA, yB, jo);
         wave_sync();
+        STAMP(3);
         if (!optimise) break; // forward-only launch (uniform)
-        w4_s2<W4_R>(idA, pkA, fr, sA);
-        w4_s2<W4_R>(idB, pkB, fr, sB);
+        t_stage(trk, fb, Lmax, last);
+        for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, Lmax, last); // (uniform, rare)
+        // the first 8 groups of bL2's weights leave LDS while stage G runs (pinned here: the scheduler would move the
+        // reads next to their use)
+        f4 wq[8];
+        load_w<8>(wq, w2);
+        __builtin_amdgcn_sched_barrier(0);
         wave_sync();
-        const f4 gyA = w4_s3<W4_R>(a, idA, pkA, Emax, iclA, fr, sA, iter, gfi, fvalid);
-        const f4 gyB = w4_s3<W4_R>(a, idB, pkB, Emax, iclB, fr, sB, iter, gfi, fvalid);
-        wave_sync(); // the next iteration's stage 1 overwrites rows stage 3 has read
+        STAMP(4);
+        f4 gyA, gyB;
+        g_stage(pc, fb, jo, tmask, Emax, gyA, gyB);
+        if (DBG_DUMP && a.dbg && iter == 0 && fvalid) {
+            if (pc.itemA >= 0) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_GY + 4 * pc.itemA) = gyA;
+            if (pc.itemB >= 0) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_GY + 4 * pc.itemB) = gyB;
+        }
+        STAMP(5);
 
-        // ================= bL2: d1 = (A2^T gy) * lrelu'(a1): K = 4 channels of items 0..15 (gyA), then items 16..25 (gyB)
+        // ================= bL2: d1 = (A2^T gy) * lrelu'(a1): K = 4 channels of the 16 side-A items (gyA), then of side-B
+        // quads 1..10 (gyB); weights streamed in chunks of 8 / 10 groups, each requested before the previous chunk's MFMAs
         acc0 = splat(0.f); acc1 = splat(0.f);
-        chain<16, 0>(acc0, acc1, gyA, w + (S_B2 / 4) * 64);
-        chain<10, 0>(acc0, acc1, gyB, w + (S_B2 / 4 + 16) * 64);
+        {
+            f4 wr[8];
+            load_w<8>(wr, w2 + 8 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            chain_begin();
+            chain_v<8, 0>(acc0, acc1, gyA, wq);
+            f4 ws[10];
+            load_w<10>(ws, w2 + 16 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            chain_v<8, 8>(acc0, acc1, gyA, wr);
+            chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
+            chain_end(acc0, acc1);
+        }
         x = dlrelu4(a1D, acc0 + acc1);
         quad_transpose(x);
-        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)
+        STAMP(6);
+        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0); bL0's weights leave LDS meanwhile
+        f4 wz[10];
+        load_w<10>(wz, w0);
+        __builtin_amdgcn_sched_barrier(0);
         acc0 = splat(0.f); acc1 = splat(0.f);
-        chain<15, 0>(acc0, acc1, x, w + (S_B1 / 4) * 64);
+        chain_begin();
+        chain_a<15, 0>(acc0, acc1, x, wB1);
+        chain_end(acc0, acc1);
         x = dlrelu4(a0D, acc0 + acc1);
         quad_transpose(x);
+        STAMP(7);
         // ================= bL0 + Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
         acc0 = splat(0.f); acc1 = splat(0.f);
-        chain<10, 0>(acc0, acc1, x, w + (S_B0 / 4) * 64);
+        chain_begin();
+        chain_v<10, 0>(acc0, acc1, x, wz);
+        chain_end(acc0, acc1);
         const f4 g = (acc0 + acc1) + a.ctmp * (zD - ztD);
+        STAMP(8);
         if (DBG_DUMP && a.dbg && iter == 0 && lane < LAT) {
 #pragma unroll
             for (int r = 0; r < FPW; ++r)
@@ -481,10 +638,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                           __builtin_amdgcn_sqrtf(vD.w)} * rbc2s + a.eps;
         zD = zD - step * (mD * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
                                   __builtin_amdgcn_rcpf(den.w)});
+        STAMP(9);
     }
+    prof.store(a.dbg, tid, blockIdx.x);
 
-    // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers, bones / qw / d and
-    // the tracker loss terms in the frame blocks)
+    // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
+    // bones and the tracker loss terms in the frame blocks)
     if (!optimise) zpreD = zD;
     if (lane < LAT) {
 #pragma unroll
@@ -495,8 +654,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     }
     wave_sync();
     if (fvalid) {
-        w4_outputs<W4_R>(a, idA, iclA, yA, fr, itA, gfi, optimise, fb + FB_ZPRE, fb + FB_ZT);
-        w4_outputs<W4_R>(a, idB, iclB, yB, fr, itB, gfi, optimise, fb + FB_ZPRE, fb + FB_ZT);
+        w4_outputs(a, pp, 0, yA, fb, gfi, optimise, cur, tmask);
+        w4_outputs(a, pp, 1, yB, fb, gfi, optimise, cur, tmask);
     }
     if (optimise && lane < LAT) {
 #pragma unroll

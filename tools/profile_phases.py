@@ -13,6 +13,10 @@ from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
 
 NAMES = ["L0 mfma", "bar1", "L1 load+mfma", "bar2", "L2 load+mfma", "bar3", "P3a normalise/bones", "P3b tracker terms",
          "P3c gather/backward/out", "bar4", "bL2", "bar5", "bL1", "bar6", "bL0", "bar7", "Adam"]
+NAMES_W4 = ["L0 (transpose, 24 steps, lrelu)", "L1 (40 steps)", "L2 (120 steps, 2 transposes)", "P3 stage 1 normalise/bones", "P3 stage 2 tracker terms",
+            "P3 stage 3 gather/backward", "bL2 (104 steps)", "bL1 (60 steps)", "bL0 (40 steps)", "Adam"]
+if os.environ.get("DP_KERNEL") == "w4":
+    NAMES = NAMES_W4
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 MAXT = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # tracker hint: > 0 selects dp_kernel4 (DP_KERNEL=4x1|4x2 forces a variant)
 N = 50
@@ -28,7 +32,7 @@ fpb, tpb, _ = opt.kernel_geometry()
 grid = (B + fpb - 1) // fpb
 print(f"kernel: {fpb} frames / {tpb} threads per workgroup, {grid} workgroups")
 raw = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20).astype(np.float64) / N
-p = raw[:, :17]
+p = raw[:, :len(NAMES)]
 tot = raw.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(NAMES):
