@@ -220,6 +220,7 @@ extern "C" int dp_debug_pack(const dp_folded* f, const int* parents, float* wfra
 // (items 0..21), of the root displacement (22) or of a virtual copy of a joint with a second / third child (23..25).
 static int w4_src_row(const ItemPlan& pl, int item, int c)
 { // row of A2 that feeds channel c of `item`, or -1
+    if (item < 0) return -1;
     if (item < NJ) return 4 * item + c;
     if (item == ITEM_DISP) return 4 * ITEM_DISP + c; // 88..91 (91: the decoder's unused fourth displacement channel)
     const int v = item - ITEM_VIRT0;
@@ -227,37 +228,48 @@ static int w4_src_row(const ItemPlan& pl, int item, int c)
     return -1;
 }
 
-extern "C" int dp_debug_pack_w4(const dp_folded* f, const int* parents, float* img, float* bias)
+extern "C" int dp_debug_pack_w4(const dp_folded* f, const dp_model* m, float* img, float* bias)
 {
-    if (!f || !parents || !img || !bias) return DP_ERR_INVALID;
+    if (!f || !model_ptrs_ok(m) || !img || !bias) return DP_ERR_INVALID;
     ItemPlan pl;
     std::string err;
-    int rc = plan_items(parents, pl, err);
+    int rc = plan_items(m->parents, pl, err);
     if (rc != DP_OK) return fail(nullptr, rc, err);
     std::memset(img, 0, sizeof(float) * dpw4::IMG_FLOATS);
     std::memset(bias, 0, sizeof(float) * dpw4::BIAS_FLOATS);
     auto put = [&](int step, int lane, float v) { img[((step >> 2) * 64 + lane) * 4 + (step & 3)] = v; };
+    // The de-normalisation of the decoder's last layer (drag_pose.py:84-85: r = y * sigma + mu) is folded into it:
+    // rows of A2 scaled by sigma, bias sigma * b2 + mu; its transpose carries the same scaling (dL/dy = sigma * dL/dr).
+    auto sd_of = [&](int item, int c) -> double {
+        if (item == ITEM_DISP) return c < 3 ? (double)m->std_disp[c] : 0.0;
+        const int r = w4_src_row(pl, item, c);
+        return r >= 0 ? (double)m->std_q[r] : 0.0;
+    };
+    auto mu_of = [&](int item, int c) -> double {
+        if (item == ITEM_DISP) return c < 3 ? (double)m->mean_disp[c] : 0.0;
+        const int r = w4_src_row(pl, item, c);
+        return r >= 0 ? (double)m->mean_q[r] : (c == 0 ? 1.0 : 0.0); // idle rows decode to the unit quaternion
+    };
     for (int l = 0; l < 64; ++l) {
         for (int k = 0; k < 24; ++k) put(dpw4::S_L0 + k, l, l < 40 ? f->A0[l * 24 + k] : 0.f);
         for (int k = 0; k < 40; ++k) put(dpw4::S_L1 + k, l, l < 60 ? f->A1[l * 40 + k] : 0.f);
-        const int ib = dpw4::item_of(1, l >> 2);
-        const int ra = w4_src_row(pl, dpw4::item_of(0, l >> 2), l & 3), rb = ib >= 0 ? w4_src_row(pl, ib, l & 3) : -1;
+        const int ia = dpw4::item_of(0, l >> 2), ib = dpw4::item_of(1, l >> 2), c = l & 3;
+        const int ra = w4_src_row(pl, ia, c), rb = ib >= 0 ? w4_src_row(pl, ib, c) : -1;
         for (int k = 0; k < 60; ++k) {
-            put(dpw4::S_L2A + k, l, ra >= 0 ? f->A2[ra * 60 + k] : 0.f);
-            put(dpw4::S_L2B + k, l, rb >= 0 ? f->A2[rb * 60 + k] : 0.f);
+            put(dpw4::S_L2A + k, l, ra >= 0 ? (float)(sd_of(ia, c) * (double)f->A2[ra * 60 + k]) : 0.f);
+            put(dpw4::S_L2B + k, l, rb >= 0 ? (float)(sd_of(ib, c) * (double)f->A2[rb * 60 + k]) : 0.f);
         }
-        for (int k = 0; k < 104; ++k) { // column k = channel k & 3 of an item of dL/dy (side A quads 0..15, then side B quads 1..10);
+        for (int k = 0; k < 104; ++k) { // column k = channel k & 3 of an item of dL/dr (side A quads 0..15, then side B quads 1..10)
             const int item = k < 64 ? dpw4::item_of(0, k >> 2) : dpw4::item_of(1, dpw4::B2_ABID0_B + ((k - 64) >> 2));
             const int r = w4_src_row(pl, item, k & 3);
-            const bool dead = item == ITEM_DISP && (k & 3) == 3; // the displacement's 4th channel carries nothing
-            put(dpw4::S_B2 + k, l, (l < 60 && r >= 0 && !dead) ? f->A2[r * 60 + l] : 0.f);
+            put(dpw4::S_B2 + k, l, (l < 60 && r >= 0) ? (float)(sd_of(item, k & 3) * (double)f->A2[r * 60 + l]) : 0.f);
         }
         for (int k = 0; k < 60; ++k) put(dpw4::S_B1 + k, l, l < 40 ? f->A1[k * 40 + l] : 0.f);
         for (int k = 0; k < 40; ++k) put(dpw4::S_B0 + k, l, l < 24 ? f->A0[k * 24 + l] : 0.f);
         bias[l] = l < 40 ? f->c0[l] : 0.f;
         bias[64 + l] = l < 60 ? f->b1[l] : 0.f;
-        bias[128 + l] = ra >= 0 ? f->b2[ra] : 0.f;
-        bias[192 + l] = rb >= 0 ? f->b2[rb] : 0.f;
+        bias[128 + l] = (float)(sd_of(ia, c) * (ra >= 0 ? (double)f->b2[ra] : 0.0) + mu_of(ia, c));
+        bias[192 + l] = ib >= 0 ? (float)(sd_of(ib, c) * (rb >= 0 ? (double)f->b2[rb] : 0.0) + mu_of(ib, c)) : (c == 0 ? 1.f : 0.f);
     }
     return DP_OK;
 }
@@ -386,7 +398,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     std::vector<ItemConst> items(32);
     std::vector<float> w4img(dpw4::IMG_FLOATS), w4bias(dpw4::BIAS_FLOATS);
     if (rc == DP_OK) rc = dp_debug_pack(&ctx->folded, model->parents, wfrag.data(), bfrag.data(), ctx->smask.data());
-    if (rc == DP_OK) rc = dp_debug_pack_w4(&ctx->folded, model->parents, w4img.data(), w4bias.data());
+    if (rc == DP_OK) rc = dp_debug_pack_w4(&ctx->folded, model, w4img.data(), w4bias.data());
     if (rc == DP_OK) rc = dp_debug_items(model, items.data());
     std::vector<dpw4::Pair> pairs(16);
     if (rc == DP_OK) rc = dp_debug_pairs_w4(model, pairs.data());

@@ -54,7 +54,8 @@ static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && F
 constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26, GR_B0 = S_B0 / 4, NG_B0 = 10; // streamed products: first group, groups
 constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
 constexpr int L_IMG0 = L_IMG2 + NG_B2 * 256;    // bL0 image [10][64][4]
-constexpr int L_FR = L_IMG0 + NG_B0 * 256;      // frame blocks [NW * 4][FB_STRIDE]
+constexpr int L_TAB = L_IMG0 + NG_B0 * 256;     // per-iteration Adam scalars [MAX_ITERS][2]: step, 1/sqrt(1-beta2^t)
+constexpr int L_FR = L_TAB + 2 * MAX_ITERS;     // frame blocks [NW * 4][FB_STRIDE]
 template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE; }
 
 // ------------------------------------------------------------------------------------------------
@@ -100,8 +101,8 @@ template <int NG> DEV void load_w(f4 (&wv)[NG], const f4* w)
 DEV void quad_transpose(f4& r)
 {
     const unsigned long long even1 = 0x5555555555555555ull, even2 = 0x3333333333333333ull;
-    float n0, n1, n2, n3, m0, m1, m2, m3;
-    asm volatile("s_mov_b64 vcc, %8\n\t"
+    float n0, n1, n2, n3, m0, m1, m2, m3; // (not volatile: pure functions of their inputs; independent transposes may interleave)
+    asm("s_mov_b64 vcc, %8\n\t"
                  "s_nop 0\n\t"
                  "v_cndmask_b32_dpp %0, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "v_cndmask_b32_dpp %2, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -111,7 +112,7 @@ DEV void quad_transpose(f4& r)
                  : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
                  : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "s"(even1)
                  : "vcc");
-    asm volatile("s_mov_b64 vcc, %8\n\t"
+    asm("s_mov_b64 vcc, %8\n\t"
                  "s_nop 0\n\t"
                  "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
@@ -131,7 +132,7 @@ DEV f2 splat2(float v) { return f2{v, v}; }
 // Kinematics.  Quaternions are (w, v) = (w, x, y, z), Hamilton; R(q) a = a + 2 (w (v x a) + v x (v x a)) is the rotation
 // to_matrix_4 (utils.py:49-74) encodes for unit q.
 struct PairC { // loop-invariant constants of my quad's two items, side A | side B packed (registers)
-    f2 sd[4], mu[4], off[3], sgn, rho, sel[6];
+    f2 off[3], sgn, rho, sel[6];
     unsigned subA, subB; // tracker subsets of the two items (general path: more than 6 trackers in a frame)
     int qsA, qsB;        // float index of my items' quaternion slots in the frame block
     int bnA, bnB;        //                          child-bone slots
@@ -235,20 +236,25 @@ DEV TRec load_tracker(const KArgs& a, const float* fb, int E, int rank)
     return t;
 }
 
-DEV int path_len(unsigned plo, unsigned phi)
+// four / three separate registers -> consecutive LDS words.  (Plain stores get merged into ds_write_b128 / b96, whose data
+// operand is a register tuple: the packed arithmetic leaves every value in a pair with the OTHER item's, so each such
+// store costs four v_mov.  ds_write2_b32 takes two unrelated registers.)  LDS operations of a wave execute in order.
+DEV void lds_store4(float* p, float a, float b, float c, float d)
 {
-    int n = 0;
-    for (int k = 0; k < MAX_PATH; ++k) n += (((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)) != (unsigned)SLOT_ZERO) ? 1 : 0;
-    return n;
+    const unsigned ad = (unsigned)(size_t)p;
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3" : : "v"(ad), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
+}
+DEV void lds_store3(float* p, float a, float b, float c)
+{
+    const unsigned ad = (unsigned)(size_t)p;
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write_b32 %0, %3 offset:8" : : "v"(ad), "v"(a), "v"(b), "v"(c) : "memory");
 }
 
 // ---- stage J: both items of my quad, packed
 struct JOut { f2 q[4], u[3], inv; };
 DEV void j_stage(const PairC& c, float* fb, const f4 yA, const f4 yB, JOut& o)
 {
-    f2 rq[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) rq[k] = f2{yA[k], yB[k]} * c.sd[k] + c.mu[k];
+    const f2 rq[4] = {f2{yA[0], yB[0]}, f2{yA[1], yB[1]}, f2{yA[2], yB[2]}, f2{yA[3], yB[3]}}; // (de-normalised by layer 2 itself)
     const f2 nn = rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3];
     const float invA = __builtin_amdgcn_rsqf(nn.x);
     const float invB = c.kindB == KIND_DISP ? 1.f : (c.kindB == KIND_IDLE ? 0.f : __builtin_amdgcn_rsqf(nn.y));
@@ -262,26 +268,26 @@ DEV void j_stage(const PairC& c, float* fb, const f4 yA, const f4 yB, JOut& o)
     o.u[0] = c.off[0] + 2.f * (w * tx + cx);
     o.u[1] = c.off[1] + 2.f * (w * ty + cy);
     o.u[2] = c.off[2] + 2.f * (w * tz + cz);
-    float* qa = fb + c.qsA; float* qb = fb + c.qsB; float* ba = fb + c.bnA; float* bb = fb + c.bnB;
-    qa[0] = o.q[0].x; qa[1] = o.q[1].x; qa[2] = o.q[2].x; qa[3] = o.q[3].x;
-    qb[0] = o.q[0].y; qb[1] = o.q[1].y; qb[2] = o.q[2].y; qb[3] = o.q[3].y;
-    ba[0] = o.u[0].x; ba[1] = o.u[1].x; ba[2] = o.u[2].x;
-    bb[0] = o.u[0].y; bb[1] = o.u[1].y; bb[2] = o.u[2].y;
+    lds_store4(fb + c.qsA, o.q[0].x, o.q[1].x, o.q[2].x, o.q[3].x);
+    lds_store4(fb + c.qsB, o.q[0].y, o.q[1].y, o.q[2].y, o.q[3].y);
+    lds_store3(fb + c.bnA, o.u[0].x, o.u[1].x, o.u[2].x);
+    lds_store3(fb + c.bnB, o.u[0].y, o.u[1].y, o.u[2].y);
 }
 
 // ---- stage T: one tracker per lane
-DEV void t_stage(const TRec& t, float* fb, int Lmax, bool losses)
+DEV void t_stage(const TRec& t, float* fb, bool losses)
 {
     if (!t.act) return;
     const f4 q0v = *(const f4*)(fb + FB_QS), qtv = *(const f4*)(fb + t.qs), dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
-    V3 p = {dv.x, dv.y, dv.z}; // root-frame position: displacement + the bones on the path
+    V3 p = {dv.x, dv.y, dv.z}; // root-frame position: displacement + the bones on the path (short paths end in the zero slot)
+    {
+        unsigned plo = t.plo, phi = t.phi;
+        asm volatile("" : "+v"(plo), "+v"(phi)); // opaque per iteration: seven hoisted slot addresses would be seven more live registers
+        f4 bn[MAX_PATH]; // all reads in flight together: one LDS latency, not seven
 #pragma unroll
-    for (int k = 0; k < MAX_PATH; ++k) {
-        if (k < Lmax) { // (uniform)
-            const unsigned s = (k < 6) ? ((t.plo >> (5 * k)) & 31u) : (t.phi & 31u);
-            const f4 bn = *(const f4*)(fb + FB_BN + 4 * s);
-            p.x += bn.x; p.y += bn.y; p.z += bn.z;
-        }
+        for (int k = 0; k < MAX_PATH; ++k) bn[k] = *(const f4*)(fb + FB_BN + 4 * ((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)));
+#pragma unroll
+        for (int k = 0; k < MAX_PATH; ++k) { p.x += bn[k].x; p.y += bn[k].y; p.z += bn[k].z; }
     }
     const Q4 q0 = {q0v.x, q0v.y, q0v.z, q0v.w};
     const V3 at = rot_conj(q0, t.tp); // target position in the root frame
@@ -337,23 +343,24 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
     const f2 g1 = w * a0 + c.sgn * (a1 * vz - a2 * vy);
     const f2 g2 = w * a1 + c.sgn * (a2 * vx - a0 * vz);
     const f2 g3 = w * a2 + c.sgn * (a0 * vy - a1 * vx);
-    // through the normalisation (already tangent: no projection) and the de-normalisation
+    // through the normalisation (already tangent: no projection); the de-normalisation is part of bL2's weights
     const f2 si = j.inv;
-    f2 y0 = c.sd[0] * (g0 * si), y1 = c.sd[1] * (g1 * si), y2 = c.sd[2] * (g2 * si), y3 = c.sd[3] * (g3 * si);
-    if (c.kindB == KIND_DISP) { y0.y = c.sd[0].y * S[0].y; y1.y = c.sd[1].y * S[1].y; y2.y = c.sd[2].y * S[2].y; y3.y = 0.f; }
+    f2 y0 = g0 * si, y1 = g1 * si, y2 = g2 * si, y3 = g3 * si;
+    if (c.kindB == KIND_DISP) { y0.y = S[0].y; y1.y = S[1].y; y2.y = S[2].y; y3.y = 0.f; }
     gyA = f4{y0.x, y1.x, y2.x, y3.x};
     gyB = f4{y0.y, y1.y, y2.y, y3.y};
 }
 
-// ---- outputs of the LAST forward pass of (item, frame gf) from its decoder quad and the frame block (reference:
-// drag_pose.py:84-113 and what run() returns); kept simple, it runs once
-DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const f4 y4, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask)
+// ---- outputs of the LAST forward pass of (item, frame gf) from the frame block (reference: drag_pose.py:84-113 and what
+// run() returns); kept simple, it runs once
+DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask)
 {
     const int item = pp->item[side], kind = pp->kind[side];
     if (item < 0 || kind == KIND_IDLE || kind == KIND_VIRT) return;
     const f4 sd = {pp->sd[0][side], pp->sd[1][side], pp->sd[2][side], pp->sd[3][side]};
     const f4 mu = {pp->mu[0][side], pp->mu[1][side], pp->mu[2][side], pp->mu[3][side]};
-    const Q4 rq = {y4.x * sd.x + mu.x, y4.y * sd.y + mu.y, y4.z * sd.z + mu.z, y4.w * sd.w + mu.w};
+    const f4 qv = *(const f4*)(fb + FB_QS + 4 * item); // what stage J of the last forward pass left: unit quaternion / displacement
+    const Q4 rq = {qv.x, qv.y, qv.z, qv.w};
     const f4 q0v = *(const f4*)(fb + FB_QS);
     const Q4 qw = quat_mul(cur, Q4{q0v.x, q0v.y, q0v.z, q0v.w}); // world rotation (drag_pose.py:88)
     const M3 R0 = quat_to_mat(qw);
@@ -365,8 +372,7 @@ DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const f4 y4, const
         }
         return;
     }
-    const float inv = __builtin_amdgcn_rsqf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);
-    const Q4 q = {rq.w * inv, rq.x * inv, rq.y * inv, rq.z * inv};
+    const Q4 q = rq;
     if (a.pose) {
         float* o = a.pose + (size_t)gf * 88 + 4 * item;
         o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y; o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
@@ -414,6 +420,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[lds_total<NW>()];
 
+#ifdef DP_PROFILE
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -425,6 +434,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     // ---- streamed weight images into LDS (the only data the waves of a workgroup share); frame blocks zeroed
     for (int k = tid; k < NG_B2 * 64; k += NW * 64) ((f4*)(lds + L_IMG2))[k] = ((const f4*)a.w4img)[GR_B2 * 64 + k];
     for (int k = tid; k < NG_B0 * 64; k += NW * 64) ((f4*)(lds + L_IMG0))[k] = ((const f4*)a.w4img)[GR_B0 * 64 + k];
+    for (int k = tid; k < a.n_iter; k += NW * 64) *(f2*)(lds + L_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]};
     float* fb0 = lds + L_FR + wave * FPW * FB_STRIDE; // this wave's four frame blocks
     for (int k = lane; k < FPW * FB_STRIDE; k += 64) fb0[k] = 0.f;
     __syncthreads();
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const float bias0 = a.w4bias[lane], bias1 = a.w4bias[64 + lane], bias2a = a.w4bias[128 + lane], bias2b = a.w4bias[192 + lane];
 
     // ---- latent and Adam state in the D layout of the last product: lane = latent dim, register r = frame f0 + r
-    f4 zD = {0.f, 0.f, 0.f, 0.f}, ztD = zD, mD = zD, vD = zD, zpreD = zD;
+    f4 zD = {0.f, 0.f, 0.f, 0.f}, ztD = zD, mD = zD, vD = zD;
     if (lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
@@ -451,8 +461,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     // ---- kinematics constants of my quad's two items
     const Pair* pp = a.w4pairs + b;
     PairC pc;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { pc.sd[k] = f2{pp->sd[k][0], pp->sd[k][1]}; pc.mu[k] = f2{pp->mu[k][0], pp->mu[k][1]}; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) pc.off[k] = f2{pp->off[k][0], pp->off[k][1]};
     pc.sgn = f2{pp->sgn[0], pp->sgn[1]};
@@ -484,19 +492,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             m &= m - 1u;
         }
     }
-    Q4 cur = {1.f, 0.f, 0.f, 0.f};
+    TRec trk;
     {
         const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
-        cur = {cv.x, cv.y, cv.z, cv.w};
-    }
-    const TRec trk = make_tracker(a, fb, gfi, tmask, E, b, cur); // lane 4u+i: tracker of rank u of frame i
-    for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur);
-    int Lmax = 0;
-    for (int base = 0; base < Emax; base += 16) {
-        const TRec t = base == 0 ? trk : load_tracker(a, fb, E, base + b);
-        const int len = t.act ? path_len(t.plo, t.phi) : 0;
-        for (int k = 1; k <= MAX_PATH; ++k)
-            if (__ballot(len >= k) != 0ull) Lmax = max(Lmax, k);
+        const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
+        trk = make_tracker(a, fb, gfi, tmask, E, b, cur); // lane 4u+i: tracker of rank u of frame i
+        for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur);
     }
     if (b == 0) *(f4*)(fb + FB_QS + 4 * QS_IDENT) = f4{1.f, 0.f, 0.f, 0.f};
     if (b < MAX_ROOT_CH) { // constant root-frame bones of the root's children
@@ -517,13 +518,16 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     }
     wave_sync();
 
-    f4 yA = {0.f, 0.f, 0.f, 0.f}, yB = yA;
     JOut jo;
     Prof prof;
     prof.start();
+#ifdef DP_PROFILE
+    prof.t[10] = prof.prev - t_entry; // kernel entry -> first iteration
+#endif
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
-        const float step = a.tab.step[iter], rbc2s = a.tab.bc2s[iter];
+        const f2 adam_t = *(const f2*)(lds + L_TAB + 2 * iter); // (an LDS broadcast read, issued a whole iteration ahead of its use)
+        const float step = adam_t.x, rbc2s = adam_t.y;
         int o = lane;
         asm volatile("" : "+v"(o)); // opaque per iteration: keeps the streamed weight reads inside the loop
         const f4* w2 = (const f4*)(lds + L_IMG2) + o;
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         // ================= L2: y = A2 a1 + b2, two 64-row blocks (side A | side B items)
         x = a1D;
         quad_transpose(x);
+        f4 yA, yB;
         {
             f4 pa0 = splat(bias2a), pa1 = splat(0.f), pb0 = splat(bias2b), pb1 = splat(0.f);
             chain_begin();
@@ -564,47 +569,37 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         STAMP(2);
 
         // ================= kinematics
-        if (DBG_DUMP && a.dbg && iter == 0 && fvalid) {
-            if (pc.itemA >= 0) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_Y + 4 * pc.itemA) = yA;
-            if (pc.itemB >= 0 && pc.kindB != KIND_VIRT) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_Y + 4 * pc.itemB) = yB;
-        }
         j_stage(pc, fb, yA, yB, jo);
         wave_sync();
         STAMP(3);
         if (!optimise) break; // forward-only launch (uniform)
-        t_stage(trk, fb, Lmax, last);
-        for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, Lmax, last); // (uniform, rare)
-        // the first 8 groups of bL2's weights leave LDS while stage G runs (pinned here: the scheduler would move the
-        // reads next to their use)
-        f4 wq[8];
+        t_stage(trk, fb, last);
+        for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, last); // (uniform, rare)
+        // bL2's weights leave LDS in three chunks (a read costs the wave its issue time wherever it stands -- the four waves of
+        // a workgroup want the same LDS cycles -- so the chunks only have to be requested a phase ahead of their use, and be
+        // small enough for the register file): 8 groups across stage G, 8 ahead of the chain, 10 behind its first chunk (each
+        // pinned: the scheduler would move the reads next to their use)
+        f4 wq[8], wr[8], ws[10];
         load_w<8>(wq, w2);
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
         STAMP(4);
         f4 gyA, gyB;
         g_stage(pc, fb, jo, tmask, Emax, gyA, gyB);
-        if (DBG_DUMP && a.dbg && iter == 0 && fvalid) {
-            if (pc.itemA >= 0) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_GY + 4 * pc.itemA) = gyA;
-            if (pc.itemB >= 0) *(f4*)(a.dbg + (size_t)gfi * DBG_STRIDE + DBG_GY + 4 * pc.itemB) = gyB;
-        }
         STAMP(5);
 
         // ================= bL2: d1 = (A2^T gy) * lrelu'(a1): K = 4 channels of the 16 side-A items (gyA), then of side-B
-        // quads 1..10 (gyB); weights streamed in chunks of 8 / 10 groups, each requested before the previous chunk's MFMAs
+        // quads 1..10 (gyB)
+        load_w<8>(wr, w2 + 8 * 64);
+        __builtin_amdgcn_sched_barrier(0);
         acc0 = splat(0.f); acc1 = splat(0.f);
-        {
-            f4 wr[8];
-            load_w<8>(wr, w2 + 8 * 64);
-            __builtin_amdgcn_sched_barrier(0);
-            chain_begin();
-            chain_v<8, 0>(acc0, acc1, gyA, wq);
-            f4 ws[10];
-            load_w<10>(ws, w2 + 16 * 64);
-            __builtin_amdgcn_sched_barrier(0);
-            chain_v<8, 8>(acc0, acc1, gyA, wr);
-            chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
-            chain_end(acc0, acc1);
-        }
+        chain_begin();
+        chain_v<8, 0>(acc0, acc1, gyA, wq);
+        load_w<10>(ws, w2 + 16 * 64); // (into the registers the first chunk has just released)
+        __builtin_amdgcn_sched_barrier(0);
+        chain_v<8, 8>(acc0, acc1, gyA, wr);
+        chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
+        chain_end(acc0, acc1);
         x = dlrelu4(a1D, acc0 + acc1);
         quad_transpose(x);
         STAMP(6);
@@ -631,7 +626,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             for (int r = 0; r < FPW; ++r)
                 if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + lane] = g[r];
         }
-        if (last) zpreD = zD; // latent of this (the last) forward pass
+        if (last && lane < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
+#pragma unroll
+            for (int r = 0; r < FPW; ++r) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r];
+        }
         mD = mD + a.one_m_b1 * (g - mD);
         vD = vD * a.beta2 + a.one_m_b2 * (g * g);
         const f4 den = f4{__builtin_amdgcn_sqrtf(vD.x), __builtin_amdgcn_sqrtf(vD.y), __builtin_amdgcn_sqrtf(vD.z),
@@ -640,33 +638,37 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                                   __builtin_amdgcn_rcpf(den.w)});
         STAMP(9);
     }
-    prof.store(a.dbg, tid, blockIdx.x);
-
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
-    if (!optimise) zpreD = zD;
     if (lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
-            fb0[r * FB_STRIDE + FB_ZPRE + lane] = zpreD[r];
+            if (!optimise) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r];
             fb0[r * FB_STRIDE + FB_ZT + lane] = ztD[r];
         }
     }
     wave_sync();
     if (fvalid) {
-        w4_outputs(a, pp, 0, yA, fb, gfi, optimise, cur, tmask);
-        w4_outputs(a, pp, 1, yB, fb, gfi, optimise, cur, tmask);
+        const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
+        const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
+        w4_outputs(a, pp, 0, fb, gfi, optimise, cur, tmask);
+        w4_outputs(a, pp, 1, fb, gfi, optimise, cur, tmask);
     }
     if (optimise && lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
             if (f0 + r < nB) {
                 if (a.z) a.z[(size_t)(f0 + r) * LAT + lane] = zD[r];
-                if (a.z_pre) a.z_pre[(size_t)(f0 + r) * LAT + lane] = zpreD[r];
+                if (a.z_pre) a.z_pre[(size_t)(f0 + r) * LAT + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
             }
         }
     }
     if (optimise && a.iters && lane < FPW && f0 + lane < nB) a.iters[f0 + lane] = a.n_iter;
+#ifdef DP_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the epilogue's stores have left the wave
+    STAMP(11);
+    prof.store(a.dbg, tid, blockIdx.x);
+#endif
 }
 
 extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream)

@@ -37,5 +37,8 @@ tot = raw.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:26s} {p[:, i].mean():8.0f}  {100 * p[:, i].mean() / tot.mean():5.1f}%")
-if raw[:, 17:].any():  # ad-hoc sub-stamps (slots 17..19) of an experiment
+if os.environ.get("DP_KERNEL") == "w4":
+    print(f"  per launch: entry -> first iteration {raw[:, 10].mean() * N:.0f} cycles, last iteration -> stores done {raw[:, 11].mean() * N:.0f} cycles "
+          f"(max over workgroups {raw[:, 10].max() * N:.0f} / {raw[:, 11].max() * N:.0f})")
+elif raw[:, 17:].any():  # ad-hoc sub-stamps (slots 17..19) of an experiment
     print("  extra stamps 16..19:", " ".join(f"{raw[:, i].mean():.0f}" for i in range(16, 20)))
