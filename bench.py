@@ -206,7 +206,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(B, N),
                          "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch.json; algorithmic 9.53e6",
-                         "kernel": "dp_optimize_kernel" if tpb == 512 else f"dp_optimize_kernel4<{fpb // 8}>", "kernel_ms": kern_ms,
+                         "kernel": "dp_optimize_kernel<false>" if tpb == 512 else "dp_w4_kernel<4, false>", "kernel_ms": kern_ms,
                          "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},
                          "flop_per_launch": B * N * FLOP_PER_FRAME_ITER,
                          "hbm_algorithmic_GBps": B * 1264 / (kern_ms * 1e-3) / 1e9},

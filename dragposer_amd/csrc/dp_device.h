@@ -1,5 +1,5 @@
-// dp_device.h -- device-side helpers shared by the optimise kernels (dp_kernel.hip: 8 waves per 16-frame workgroup;
-// dp_kernel4.hip: 4 waves per workgroup, two workgroups per CU).
+// dp_device.h -- device-side helpers shared by the optimise kernels (dp_w4.hip: wave-private, the product's kernel;
+// dp_kernel.hip: the previous decomposition, 8 waves per 16-frame workgroup, kept for comparisons).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dp_kernel.h"

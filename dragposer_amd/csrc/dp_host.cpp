@@ -29,7 +29,8 @@ struct dp_ctx {
     std::vector<unsigned> smask;
     std::string err;
     float mean_q0[4] = {0, 0, 0, 0}, std_q0[4] = {1, 1, 1, 1}; // root quaternion channels (sequence epilogue)
-    int last_kernel = 0; // 8, 41 (4 waves x 8 frames) or 42 (4 waves x 16 frames): what the last launch used
+    int forced_kernel = 0; // DP_KERNEL in the environment at dp_create: 8 = the 8-wave kernel of dp_kernel.hip (comparisons)
+    int last_kernel = 0;   // 4 (wave-private, dp_w4.hip) or 8: what the last launch used
 };
 
 static thread_local std::string g_create_err;
@@ -391,6 +392,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     dp_ctx* ctx = new dp_ctx();
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = std::getenv("DP_KERNEL")) ctx->forced_kernel = !std::strcmp(e, "8") ? 8 : 0; // read once, here
     for (int k = 0; k < 4; ++k) { ctx->mean_q0[k] = model->mean_q[k]; ctx->std_q0[k] = model->std_q[k]; }
     int rc = dp_fold_decoder(model, &ctx->folded);
     std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
@@ -480,11 +482,11 @@ extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
 }
 
 extern "C" int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes)
-{ // of the kernel the context's last launch used (the 8-wave kernel before any launch)
-    const int k = ctx ? ctx->last_kernel : 0;
-    if (frames_per_block) *frames_per_block = k == 41 ? 8 : k == 4 ? dp_w4_frames_per_block() : FPB;
-    if (threads_per_block) *threads_per_block = (k == 41 || k == 42 || k == 4) ? 256 : NTHREADS;
-    if (lds_bytes) *lds_bytes = k == 4 ? dp_w4_lds_bytes() : (k == 41 || k == 42) ? dp_kernel4_lds_bytes() : dp_kernel_lds_bytes();
+{ // of the kernel the context's launches use
+    const int k = ctx && (ctx->last_kernel == 8 || (ctx->last_kernel == 0 && ctx->forced_kernel == 8)) ? 8 : 4;
+    if (frames_per_block) *frames_per_block = k == 4 ? dp_w4_frames_per_block() : FPB;
+    if (threads_per_block) *threads_per_block = k == 4 ? 256 : NTHREADS;
+    if (lds_bytes) *lds_bytes = k == 4 ? dp_w4_lds_bytes() : dp_kernel_lds_bytes();
     return DP_OK;
 }
 
@@ -507,34 +509,14 @@ static void fill_results(const dp_result* out, KArgs& k)
     k.world_rot = out->world_rot; k.pos = out->pos; k.rot = out->rot; k.loss = out->loss; k.iters = out->iters;
 }
 
-// Which kernel runs a batch (all give bit-identical results):
-//   dp_kernel.hip   8 waves, 16 frames per workgroup, one workgroup per CU -- the default
-//   dp_kernel4.hip  4 waves, 16 frames per workgroup, two workgroups per CU: a few percent more throughput once every
-//                   CU has at least two workgroups (measured +6 % at 8192 frames, +11 % at 65536); needs the caller's
-//                   max_trackers hint (<= its capacity) and a fixed iteration count.
-// DP_KERNEL=8|4x2|4x1 in the environment overrides the choice for experiments (4x1: 8-frame groups, measured slower
-// at every batch size -- the kinematics phase is bound by per-wave instruction issue, not by frames per wave).
-static int pick_kernel(const dp_ctx* ctx, const KArgs& k, int max_trackers)
+// Which kernel runs a launch: the wave-private kernel of dp_w4.hip (4 frames per wave, no workgroup barrier in the
+// loop).  DP_KERNEL=8 in the environment AT dp_create selects the previous decomposition (dp_kernel.hip: 16 frames per
+// 8-wave workgroup) for comparisons; both implement the same operator within the tolerance of tests/test_hip_w4.py.
+static int launch(dp_ctx* ctx, KArgs& k, void* stream)
 {
-    int choice = 8;
-    const bool k4_ok = !k.early_stop && (k.mode == 1 || (max_trackers > 0 && max_trackers <= dp_kernel4_max_trackers()));
-    if (k4_ok && k.n_frames > 16 * ctx->n_cu) choice = 42;
-    if (const char* e = std::getenv("DP_KERNEL")) {
-        if (!std::strcmp(e, "w4") && !k.early_stop) choice = 4;
-        else if (!std::strcmp(e, "8")) choice = 8;
-        else if (k4_ok && !std::strcmp(e, "4x1")) choice = 41;
-        else if (k4_ok && !std::strcmp(e, "4x2")) choice = 42;
-    }
-    return choice;
-}
-
-static int launch(dp_ctx* ctx, KArgs& k, void* stream, int max_trackers = 0)
-{
-    const int choice = pick_kernel(ctx, k, max_trackers);
+    const int choice = ctx->forced_kernel == 8 ? 8 : 4;
     ctx->last_kernel = choice;
-    hipError_t e = choice == 8   ? dp_launch_optimize(&k, (hipStream_t)stream)
-                   : choice == 4 ? dp_launch_w4(&k, (hipStream_t)stream)
-                                 : dp_launch_optimize4(&k, choice - 40, (hipStream_t)stream);
+    hipError_t e = choice == 8 ? dp_launch_optimize(&k, (hipStream_t)stream) : dp_launch_w4(&k, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
     return DP_OK;
 }
@@ -571,7 +553,7 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
         k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
     }
-    return launch(ctx, k, stream, p->max_trackers);
+    return launch(ctx, k, stream);
 }
 
 extern "C" int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, void* stream)

@@ -41,10 +41,6 @@ struct KArgs {
 
 extern "C" hipError_t dp_launch_optimize(const KArgs* args, hipStream_t stream);
 extern "C" int dp_kernel_lds_bytes(void);
-// dp_kernel4.hip: 4-wave workgroups, two per CU; rounds = 1 (8 frames per workgroup) or 2 (16)
-extern "C" hipError_t dp_launch_optimize4(const KArgs* args, int rounds, hipStream_t stream);
-extern "C" int dp_kernel4_lds_bytes(void);
-extern "C" int dp_kernel4_max_trackers(void);
 // dp_w4.hip: wave-private kernel, 4 frames per wave, no workgroup barrier inside the loop
 extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream);
 extern "C" int dp_w4_lds_bytes(void);

@@ -1,5 +1,5 @@
-// dp_p3.h -- the kinematics phase ("P3") of an iteration and the output epilogue, shared by both optimise kernels
-// (dp_kernel.hip, dp_kernel4.hip) so that they cannot drift apart: quaternion normalisation, root-frame FK, tracker
+// dp_p3.h -- the kinematics phase ("P3") of an iteration and the output epilogue of the 8-wave kernel (dp_kernel.hip):
+// quaternion normalisation, root-frame FK, tracker
 // loss terms, and the hand-derived backward to dL/dy (reference: DragPose.loss, python/src/drag_pose.py:66-194 with
 // utils.py:80-149, and what autograd derives from it).
 //

@@ -44,12 +44,14 @@ constexpr int FB_LP = FB_WT + 128;           // [R][2]  tracker loss terms (last
 constexpr int FB_TI = FB_LP + 2 * W4_R;      // [3][R][4] tracker inputs by rank: tp', cgp | qT' | k8, clp, clr8, joint
 constexpr int FB_ZPRE = FB_TI + 12 * W4_R;   // [24] latent of the last forward pass (epilogue only)
 constexpr int FB_ZT = FB_ZPRE + LAT;         // [24] z_tgt (epilogue only)
-constexpr int FB_END = FB_ZT + LAT;
+constexpr int FB_LT = FB_ZT + LAT;           // [24] early stop: (z - z_tgt)^2 per latent dim of the current latent
+constexpr int FB_ES = FB_LT + LAT;           // [4]  early stop: losses of the frame's last executed iteration (pos, rot, tmp, -)
+constexpr int FB_END = FB_ES + 4;
 constexpr int QS_DISP = ITEM_DISP, QS_IDENT = 30, QS_TRASH = 31, WT_ZERO = 30, WT_TRASH = 31;
 // the four frames of a wave sit in the four lanes of every quad: block stride = 16 banks (mod 64) apart, so that the
 // quad's 16-byte accesses to the same row of four blocks never share a bank
 constexpr int FB_STRIDE = ((FB_END - 16 + 63) / 64) * 64 + 16;
-static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && FB_TI % 4 == 0 && FB_ZPRE % 4 == 0, "frame block layout");
+static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && FB_TI % 4 == 0 && FB_ZPRE % 4 == 0 && FB_ES % 4 == 0, "frame block layout");
 
 constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26, GR_B0 = S_B0 / 4, NG_B0 = 10; // streamed products: first group, groups
 constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
@@ -353,7 +355,7 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
 
 // ---- outputs of the LAST forward pass of (item, frame gf) from the frame block (reference: drag_pose.py:84-113 and what
 // run() returns); kept simple, it runs once
-DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask)
+DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
 {
     const int item = pp->item[side], kind = pp->kind[side];
     if (item < 0 || kind == KIND_IDLE || kind == KIND_VIRT) return;
@@ -399,7 +401,10 @@ DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, i
     }
     if (kind == KIND_ROOT) {
         if (a.world_rot) { float* o = a.world_rot + (size_t)gf * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
-        if (optimise && a.loss) {
+        if (optimise && a.loss && early) { // losses of the frame's last executed iteration, as the stop test saw them
+            const f4 es = *(const f4*)(fb + FB_ES);
+            a.loss[(size_t)gf * 3 + 0] = es.x; a.loss[(size_t)gf * 3 + 1] = es.y; a.loss[(size_t)gf * 3 + 2] = es.z;
+        } else if (optimise && a.loss) {
             float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
             const int E = min(__popc(tmask), W4_R);
             for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(fb + FB_LP + 2 * e0); lsum_p += l.x; lsum_r += l.y; }
@@ -415,7 +420,10 @@ DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, i
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int NW>
+// EARLY: the reference's per-frame while-condition (drag_pose.py:298-304, 351-355).  A stopped frame keeps its pre-step
+// latent, so the forward passes it still takes part in reproduce its last one; a wave leaves the loop once all four of its
+// frames have stopped.
+template <int NW, bool EARLY>
 __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[lds_total<NW>()];
@@ -456,6 +464,15 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             zD[r] = a.z0[(size_t)gf * LAT + lane];
             if (optimise) ztD[r] = a.z_tgt[(size_t)gf * LAT + lane];
         }
+    }
+
+    f4 zfinD = zD;               // early stop: latent after a frame's last step
+    float es_prev = 10000000.f;  // early stop, lanes 0..3 (quad 0 = the root's) = frames: previous total loss (drag_pose.py:297),
+    bool es_act = true;          //   still iterating,
+    int es_iters = 0;            //   iterations executed
+    if (EARLY && lane < LAT) {
+#pragma unroll
+        for (int r = 0; r < FPW; ++r) { const float dz = zD[r] - ztD[r]; fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz; }
     }
 
     // ---- kinematics constants of my quad's two items
@@ -573,8 +590,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         wave_sync();
         STAMP(3);
         if (!optimise) break; // forward-only launch (uniform)
-        t_stage(trk, fb, last);
-        for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, last); // (uniform, rare)
+        t_stage(trk, fb, EARLY || last);
+        for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, EARLY || last); // (uniform, rare)
         // bL2's weights leave LDS in three chunks (a read costs the wave its issue time wherever it stands -- the four waves of
         // a workgroup want the same LDS cycles -- so the chunks only have to be requested a phase ahead of their use, and be
         // small enough for the register file): 8 groups across stage G, 8 ahead of the chain, 10 behind its first chunk (each
@@ -584,6 +601,29 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
         STAMP(4);
+        unsigned actmask = 0xFu, stopmask = 0u; // bit r: frame f0 + r runs this iteration / stops after its step
+        if (EARLY) {
+            bool was_act = false, stop_now = false;
+            if (b == 0) { // lane i: the stop test of frame i
+                float lp = 0.f, lr = 0.f, lt = 0.f;
+                for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(fb + FB_LP + 2 * e0); lp += l.x; lr += l.y; }
+#pragma unroll
+                for (int k = 0; k < LAT; k += 4) { const f4 d = *(const f4*)(fb + FB_LT + k); lt += (d.x + d.y) + (d.z + d.w); }
+                lt *= a.lam_tmp * (1.f / 24.f);
+                const float tot = (lp + lr) + lt;
+                const bool cont = (lp > a.stop_eps_pos || lr > a.stop_eps_rot) && (es_prev - tot > a.min_loss_incr) && !last;
+                was_act = es_act;
+                if (es_act) {
+                    es_prev = tot;
+                    ++es_iters;
+                    *(f4*)(fb + FB_ES) = f4{lp, lr, lt, 0.f};
+                }
+                stop_now = es_act && !cont;
+                es_act = es_act && cont;
+            }
+            actmask = (unsigned)__ballot(was_act) & 0xFu;
+            stopmask = (unsigned)__ballot(stop_now) & 0xFu;
+        }
         f4 gyA, gyB;
         g_stage(pc, fb, jo, tmask, Emax, gyA, gyB);
         STAMP(5);
@@ -626,17 +666,40 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             for (int r = 0; r < FPW; ++r)
                 if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + lane] = g[r];
         }
-        if (last && lane < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
+        if (!EARLY) {
+            if (last && lane < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
 #pragma unroll
-            for (int r = 0; r < FPW; ++r) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r];
+                for (int r = 0; r < FPW; ++r) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r];
+            }
+            mD = mD + a.one_m_b1 * (g - mD);
+            vD = vD * a.beta2 + a.one_m_b2 * (g * g);
+            const f4 den = f4{__builtin_amdgcn_sqrtf(vD.x), __builtin_amdgcn_sqrtf(vD.y), __builtin_amdgcn_sqrtf(vD.z),
+                              __builtin_amdgcn_sqrtf(vD.w)} * rbc2s + a.eps;
+            zD = zD - step * (mD * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
+                                      __builtin_amdgcn_rcpf(den.w)});
+        } else {
+            const f4 mN = mD + a.one_m_b1 * (g - mD);
+            const f4 vN = vD * a.beta2 + a.one_m_b2 * (g * g);
+            const f4 den = f4{__builtin_amdgcn_sqrtf(vN.x), __builtin_amdgcn_sqrtf(vN.y), __builtin_amdgcn_sqrtf(vN.z),
+                              __builtin_amdgcn_sqrtf(vN.w)} * rbc2s + a.eps;
+            const f4 zN = zD - step * (mN * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
+                                               __builtin_amdgcn_rcpf(den.w)});
+#pragma unroll
+            for (int r = 0; r < FPW; ++r) {
+                if ((actmask >> r) & 1u) { // (uniform)
+                    if (lane < LAT) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r]; // latent of this frame's (so far) last forward pass
+                    if ((stopmask >> r) & 1u) {
+                        zfinD[r] = zN[r]; // the frame's loop ends with this step; z, m, v stay as they are
+                    } else {
+                        zD[r] = zN[r]; mD[r] = mN[r]; vD[r] = vN[r];
+                        const float dz = zN[r] - ztD[r];
+                        if (lane < LAT) fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz;
+                    }
+                }
+            }
         }
-        mD = mD + a.one_m_b1 * (g - mD);
-        vD = vD * a.beta2 + a.one_m_b2 * (g * g);
-        const f4 den = f4{__builtin_amdgcn_sqrtf(vD.x), __builtin_amdgcn_sqrtf(vD.y), __builtin_amdgcn_sqrtf(vD.z),
-                          __builtin_amdgcn_sqrtf(vD.w)} * rbc2s + a.eps;
-        zD = zD - step * (mD * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
-                                  __builtin_amdgcn_rcpf(den.w)});
         STAMP(9);
+        if (EARLY && ((unsigned)__ballot(es_act && b == 0) & 0xFu) == 0u) break; // every frame of the wave has stopped
     }
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
@@ -651,19 +714,19 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     if (fvalid) {
         const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
         const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
-        w4_outputs(a, pp, 0, fb, gfi, optimise, cur, tmask);
-        w4_outputs(a, pp, 1, fb, gfi, optimise, cur, tmask);
+        w4_outputs(a, pp, 0, fb, gfi, optimise, cur, tmask, EARLY);
+        w4_outputs(a, pp, 1, fb, gfi, optimise, cur, tmask, EARLY);
     }
     if (optimise && lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
             if (f0 + r < nB) {
-                if (a.z) a.z[(size_t)(f0 + r) * LAT + lane] = zD[r];
+                if (a.z) a.z[(size_t)(f0 + r) * LAT + lane] = EARLY ? zfinD[r] : zD[r];
                 if (a.z_pre) a.z_pre[(size_t)(f0 + r) * LAT + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
             }
         }
     }
-    if (optimise && a.iters && lane < FPW && f0 + lane < nB) a.iters[f0 + lane] = a.n_iter;
+    if (optimise && a.iters && lane < FPW && f0 + lane < nB) a.iters[f0 + lane] = EARLY ? es_iters : a.n_iter;
 #ifdef DP_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the epilogue's stores have left the wave
     STAMP(11);
@@ -675,7 +738,10 @@ extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream)
 {
     constexpr int NW = 4;
     const int grid = (args->n_frames + NW * FPW - 1) / (NW * FPW);
-    hipLaunchKernelGGL(dp_w4_kernel<NW>, dim3(grid), dim3(NW * 64), 0, stream, *args);
+    if (args->early_stop && args->mode == 0)
+        hipLaunchKernelGGL((dp_w4_kernel<NW, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    else
+        hipLaunchKernelGGL((dp_w4_kernel<NW, false>), dim3(grid), dim3(NW * 64), 0, stream, *args);
     return hipGetLastError();
 }
 

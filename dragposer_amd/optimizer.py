@@ -102,8 +102,7 @@ class LatentOptimizer:
         tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream.
         With stop_eps_* > 0 or min_loss_incr given, every frame runs the reference's own while-condition
         (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter).
-        `max_trackers`: upper bound of tracked joints per frame when the caller knows it (0 = unknown); lets the
-        library pick its two-workgroups-per-CU kernel for fixed-iteration runs (same results)."""
+        `max_trackers`: ignored (a kernel-selection hint of version 1; kept so that old callers keep working)."""
         B = int(z0.shape[0])
         dev = self.device
         batch = _lib.DpBatch()

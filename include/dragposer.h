@@ -103,10 +103,8 @@ typedef struct dp_params {
     float lambda_rot, lambda_tmp;
     int early_stop;    /* 1: per-frame while-condition of drag_pose.py:300-304 */
     float stop_eps_pos, stop_eps_rot, min_loss_incr;
-    int max_trackers;  /* hint: upper bound of tracked joints in any frame of the batch (the reference's len(mask_joints),
-                          drag_pose.py:116), or 0 when unknown.  With 1..16 and early_stop == 0 the launch uses the
-                          two-workgroups-per-CU kernel (same results bit for bit, higher throughput); trackers beyond a
-                          stated bound are ignored.  0 is always safe. */
+    int max_trackers;  /* ignored (kept for ABI compatibility with version 1, where it selected a kernel variant): every
+                          joint of a frame may carry a tracker, whatever this says */
 } dp_params;
 
 /* Outputs, DEVICE pointers; any may be NULL.  All but z are those of the LAST forward pass

@@ -70,7 +70,7 @@ def test_native_library_is_what_runs(opt):
     assert os.path.exists(_lib.LIB_PATH)
     maps = open("/proc/self/maps").read()
     assert "libdragposer_hip.so" in maps
-    assert opt.frames_per_block == 16 and opt.threads_per_block == 512
+    assert opt.frames_per_block == 16 and opt.threads_per_block == 256  # dp_w4.hip: four waves of four frames
 
 
 def test_forward_matches_oracle(opt, dev):
@@ -261,7 +261,7 @@ def test_edge_sizes(opt, dev, golden_dir):
     assert torch.isfinite(o["z"]).all() and (o["iters"] == 256).all()
     reps = 4096  # 64 golden frames x 4096 = 262 144 frames
     big = {k: v.repeat((reps,) + (1,) * (v.dim() - 1)) for k, v in d.items()}
-    for hint in (0, 6):  # both kernels
+    for hint in (0, 6):  # (the version-1 kernel hint is accepted and ignored)
         ob = opt.optimize(**big, n_iter=3, max_trackers=hint, outputs=("z", "pos", "loss"))
         os_ = opt.optimize(**d, n_iter=3, outputs=("z", "pos", "loss"))
         for k in ("z", "pos", "loss"):
