@@ -6,8 +6,8 @@
 //   * Decoder forward / backward: v_mfma_f32_4x4x1_16b_f32 with the A-block broadcast (dp_w4.h): a step is a rank-1
 //     update of a 64-channel x 4-frame tile; activations stay in registers between layers (a 4x4 register <-> lane
 //     transpose inside lane quads turns a product's result into the next product's operand).  The weights of L0, L1,
-//     L2 and bL1 stay resident in the accumulator half of the register file for the whole launch; those of bL2 and bL0
-//     are streamed from LDS (shared by the waves of a workgroup), requested a phase ahead of their use.
+//     L2, bL1 (accumulator half of the register file) and bL0 (vector half) stay resident for the whole launch; those
+//     of bL2 are streamed from LDS (shared by the waves of a workgroup), requested a phase ahead of their use.
 //   * Kinematics: three stages per iteration, two wave-level LDS exchanges between them, all inside the wave.
 //       J  lane 4b+i = the two items of quad b (dp_w4.h) of frame i, both in one packed (v_pk_*) instruction stream:
 //          de-normalise, normalise, root-frame bone of the item's child (quaternion sandwich, no matrix);
@@ -53,10 +53,9 @@ constexpr int QS_DISP = ITEM_DISP, QS_IDENT = 30, QS_TRASH = 31, WT_ZERO = 30, W
 constexpr int FB_STRIDE = ((FB_END - 16 + 63) / 64) * 64 + 16;
 static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && FB_TI % 4 == 0 && FB_ZPRE % 4 == 0 && FB_ES % 4 == 0, "frame block layout");
 
-constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26, GR_B0 = S_B0 / 4, NG_B0 = 10; // streamed products: first group, groups
+constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26;     // the streamed product: first group, groups
 constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
-constexpr int L_IMG0 = L_IMG2 + NG_B2 * 256;    // bL0 image [10][64][4]
-constexpr int L_TAB = L_IMG0 + NG_B0 * 256;     // per-iteration Adam scalars [MAX_ITERS][2]: step, 1/sqrt(1-beta2^t)
+constexpr int L_TAB = L_IMG2 + NG_B2 * 256;     // per-iteration Adam scalars [MAX_ITERS][2]: step, 1/sqrt(1-beta2^t)
 constexpr int L_FR = L_TAB + 2 * MAX_ITERS;     // frame blocks [NW * 4][FB_STRIDE]
 template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE; }
 
@@ -78,18 +77,42 @@ template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
 template <int ABID> DEV void group_a(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP_ASM("a"); }
 template <int ABID> DEV void group_v(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP_ASM("v"); }
+// first group of a chain: the accumulators START here -- acc1 (and acc0, when the product has no bias row) take the inline
+// constant 0 as their C operand instead of being cleared by eight v_mov first
+#define W4_FIRST_ASM(WC, C0, OUT0)                                                                                        \
+    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, " C0 " cbsz:4 abid:%10\n\t"                                       \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, 0 cbsz:4 abid:%10\n\t"                                            \
+                 "s_nop 0\n\t"                                                                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"                                           \
+                 "s_nop 0"                                                                                                \
+                 : OUT0(acc0), "=&v"(acc1)                                                                                \
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
+template <int ABID> DEV void first_a_biased(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("a", "%0", "+v"); }
+template <int ABID> DEV void first_a_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("a", "0", "=&v"); }
+template <int ABID> DEV void first_v_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("v", "0", "=&v"); }
 // a VALU result (transpose, kinematics) feeding the first MFMA of a chain / the chain's result feeding the VALU
 DEV void chain_begin() { asm volatile("s_nop 1"); }
 DEV void chain_end(f4& acc0, f4& acc1) { asm volatile("s_nop 3" : "+v"(acc0), "+v"(acc1)); }
 
 // NG groups from resident weights (accumulator registers) / from weights in vector registers
-template <int NG, int ABID0> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv)
+// START: 0 continues a chain; 1 starts one whose acc0 holds the bias row; 2 starts one from zero
+template <int NG, int ABID0, int START = 0> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv)
 {
-    static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; group_a<ABID0 + g>(acc0, acc1, x, wv[g]); });
+    static_for<NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (g == 0 && START == 1) first_a_biased<ABID0>(acc0, acc1, x, wv[0]);
+        else if constexpr (g == 0 && START == 2) first_a_zero<ABID0>(acc0, acc1, x, wv[0]);
+        else group_a<ABID0 + g>(acc0, acc1, x, wv[g]);
+    });
 }
-template <int NG, int ABID0> DEV void chain_v(f4& acc0, f4& acc1, const f4& x, const f4* wv)
+template <int NG, int ABID0, int START = 0> DEV void chain_v(f4& acc0, f4& acc1, const f4& x, const f4* wv)
 {
-    static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; group_v<ABID0 + g>(acc0, acc1, x, wv[g]); });
+    static_for<NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (g == 0 && START == 2) first_v_zero<ABID0>(acc0, acc1, x, wv[0]);
+        else group_v<ABID0 + g>(acc0, acc1, x, wv[g]);
+    });
 }
 template <int NG> DEV void load_w(f4 (&wv)[NG], const f4* w)
 {
@@ -283,8 +306,7 @@ DEV void t_stage(const TRec& t, float* fb, bool losses)
     const f4 q0v = *(const f4*)(fb + FB_QS), qtv = *(const f4*)(fb + t.qs), dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
     V3 p = {dv.x, dv.y, dv.z}; // root-frame position: displacement + the bones on the path (short paths end in the zero slot)
     {
-        unsigned plo = t.plo, phi = t.phi;
-        asm volatile("" : "+v"(plo), "+v"(phi)); // opaque per iteration: seven hoisted slot addresses would be seven more live registers
+        const unsigned plo = t.plo, phi = t.phi;
         f4 bn[MAX_PATH]; // all reads in flight together: one LDS latency, not seven
 #pragma unroll
         for (int k = 0; k < MAX_PATH; ++k) bn[k] = *(const f4*)(fb + FB_BN + 4 * ((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)));
@@ -301,9 +323,12 @@ DEV void t_stage(const TRec& t, float* fb, bool losses)
     const float k = t.k8 * s.w;
     const V3 own = {k * s.x, k * s.y, k * s.z}; // torque on the tracked joint (and on the root)
     const V3 ag = cross(at, gp);
-    *(f4*)(fb + FB_GP + 4 * t.rank) = f4{gp.x, gp.y, gp.z, 0.f};
-    *(f4*)(fb + FB_RT + 4 * t.rank) = f4{ag.x + own.x, ag.y + own.y, ag.z + own.z, 0.f};
-    *(f4*)(fb + t.wt) = f4{own.x, own.y, own.z, 0.f};
+    // (fourth components are never read: anything already in a register serves -- a constant there makes the register
+    //  allocator clear a register of a tuple an LDS read is still writing, and wait for it)
+    const V3 rt = {ag.x + own.x, ag.y + own.y, ag.z + own.z};
+    *(f4*)(fb + FB_GP + 4 * t.rank) = f4{gp.x, gp.y, gp.z, gp.z};
+    *(f4*)(fb + FB_RT + 4 * t.rank) = f4{rt.x, rt.y, rt.z, rt.z};
+    *(f4*)(fb + t.wt) = f4{own.x, own.y, own.z, own.z};
     if (losses) // (uniform) read by the epilogue
         *(f2*)(fb + FB_LP + 2 * t.rank) = f2{t.clp * (e.x * e.x + e.y * e.y + e.z * e.z), t.clr8 * (s.x * s.x + s.y * s.y + s.z * s.z)};
 }
@@ -383,11 +408,11 @@ DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, i
         const f4 dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
         V3 pr = {dv.x, dv.y, dv.z};
         const unsigned plo = a.items[item].path_lo, phi = a.items[item].path_hi;
-        for (int k = 0; k < MAX_PATH; ++k) {
-            const unsigned s = (k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u);
-            const f4 bn = *(const f4*)(fb + FB_BN + 4 * s);
-            pr.x += bn.x; pr.y += bn.y; pr.z += bn.z;
-        }
+        f4 bn[MAX_PATH];
+#pragma unroll
+        for (int k = 0; k < MAX_PATH; ++k) bn[k] = *(const f4*)(fb + FB_BN + 4 * ((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)));
+#pragma unroll
+        for (int k = 0; k < MAX_PATH; ++k) { pr.x += bn[k].x; pr.y += bn[k].y; pr.z += bn[k].z; }
         const V3 pw = mat_vec(R0, pr);
         float* o = a.pos + ((size_t)gf * NJ + item) * 3;
         o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
@@ -430,6 +455,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 
 #ifdef DP_PROFILE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    unsigned long long t_setup[5] = {0, 0, 0, 0, 0};
+#define SETUP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t_setup[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SETUP_STAMP(i)
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -439,13 +468,33 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const int f0 = (blockIdx.x * NW + wave) * FPW;
     const bool optimise = (a.mode == 0);
 
-    // ---- streamed weight images into LDS (the only data the waves of a workgroup share); frame blocks zeroed
+    // ---- resident weight images first: 71 loads per lane from the (L2-resident) global image, in flight while the rest of
+    //      the setup runs.  (MFMA B operands, loop-invariant: L0, L1, L2A, L2B, bL1 = 61 groups = 244 accumulator registers)
+    f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15];
+    {
+        const f4* w = (const f4*)a.w4img + lane;
+        load_w<6>(wL0, w + (S_L0 / 4) * 64);
+        load_w<10>(wL1, w + (S_L1 / 4) * 64);
+        load_w<15>(wL2A, w + (S_L2A / 4) * 64);
+        load_w<15>(wL2B, w + (S_L2B / 4) * 64);
+        load_w<15>(wB1, w + (S_B1 / 4) * 64);
+    }
+    f4 wz[10]; // bL0's weights: resident too, in VECTOR registers (measured +2 % over streaming them; the accumulator half is full)
+    load_w<10>(wz, (const f4*)a.w4img + lane + (S_B0 / 4) * 64);
+
+    // ---- the streamed weight image into LDS (the only data the waves of a workgroup share)
     for (int k = tid; k < NG_B2 * 64; k += NW * 64) ((f4*)(lds + L_IMG2))[k] = ((const f4*)a.w4img)[GR_B2 * 64 + k];
-    for (int k = tid; k < NG_B0 * 64; k += NW * 64) ((f4*)(lds + L_IMG0))[k] = ((const f4*)a.w4img)[GR_B0 * 64 + k];
     for (int k = tid; k < a.n_iter; k += NW * 64) *(f2*)(lds + L_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]};
     float* fb0 = lds + L_FR + wave * FPW * FB_STRIDE; // this wave's four frame blocks
-    for (int k = lane; k < FPW * FB_STRIDE; k += 64) fb0[k] = 0.f;
+    // what has to read as zero in a frame block: the own-torque slots of untracked joints, the two tracker tables (stage G
+    // reads rows beyond a frame's tracker count) and the bones' zero slot
+    constexpr int NZ = 32 + 2 * W4_R + 1;
+    for (int k = lane; k < FPW * NZ; k += 64) {
+        const int fr = k / NZ, r = k % NZ;
+        *(f4*)(fb0 + fr * FB_STRIDE + (r < 32 ? FB_WT + 4 * r : r < 32 + 2 * W4_R ? FB_GP + 4 * (r - 32) : FB_BN + 4 * SLOT_ZERO)) = f4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
+    SETUP_STAMP(0);
     if (f0 >= nB) return; // (uniform per wave) no barrier below this line
 
     const int gfi = min(f0 + i, nB - 1); // my frame as the lane of a quad (clamped: ragged tails compute a copy)
@@ -493,6 +542,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     pc.wtB = FB_WT + 4 * (pc.kindB == KIND_JOINT && pc.itemB >= 0 ? pc.itemB : WT_ZERO); // virtual copies only carry a bone
     pc.tab = pp->kind[0] == KIND_ROOT ? FB_RT : FB_GP;
 
+    SETUP_STAMP(1);
     // ---- trackers of my frame
     unsigned tmask = 0;
     if (optimise)
@@ -522,17 +572,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         *(f4*)(fb + FB_BN + 4 * ic->init_id) = f4{ic->init_off[0], ic->init_off[1], ic->init_off[2], 0.f};
     }
 
-    // ---- resident weight images (MFMA B operands, loop-invariant, accumulator registers): L0, L1, L2A, L2B, bL1 =
-    //      61 groups = 244 registers, straight from the (L2-resident) global image
-    f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15];
-    {
-        const f4* w = (const f4*)a.w4img + lane;
-        load_w<6>(wL0, w + (S_L0 / 4) * 64);
-        load_w<10>(wL1, w + (S_L1 / 4) * 64);
-        load_w<15>(wL2A, w + (S_L2A / 4) * 64);
-        load_w<15>(wL2B, w + (S_L2B / 4) * 64);
-        load_w<15>(wB1, w + (S_B1 / 4) * 64);
-    }
+    SETUP_STAMP(2);
     wave_sync();
 
     JOut jo;
@@ -540,6 +580,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.start();
 #ifdef DP_PROFILE
     prof.t[10] = prof.prev - t_entry; // kernel entry -> first iteration
+    prof.t[12] = t_setup[0] - t_entry;    // staging, zeroing, barrier
+    prof.t[13] = t_setup[1] - t_setup[0]; // latent, bias rows, quad constants
+    prof.t[14] = t_setup[2] - t_setup[1]; // trackers
+    prof.t[15] = prof.prev - t_setup[2];  // resident weights
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;
 #endif
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
@@ -548,23 +593,22 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         int o = lane;
         asm volatile("" : "+v"(o)); // opaque per iteration: keeps the streamed weight reads inside the loop
         const f4* w2 = (const f4*)(lds + L_IMG2) + o;
-        const f4* w0 = (const f4*)(lds + L_IMG0) + o;
 
         // ================= L0: a0 = lrelu(A0 z + c0)
         f4 x = zD;
         quad_transpose(x);
-        f4 acc0 = splat(bias0), acc1 = splat(0.f);
+        f4 acc0 = splat(bias0), acc1;
         chain_begin();
-        chain_a<6, 0>(acc0, acc1, x, wL0);
+        chain_a<6, 0, 1>(acc0, acc1, x, wL0);
         chain_end(acc0, acc1);
         const f4 a0D = lrelu4(acc0 + acc1);
         STAMP(0);
         // ================= L1: a1 = lrelu(A1 a0 + b1)
         x = a0D;
         quad_transpose(x);
-        acc0 = splat(bias1); acc1 = splat(0.f);
+        acc0 = splat(bias1);
         chain_begin();
-        chain_a<10, 0>(acc0, acc1, x, wL1);
+        chain_a<10, 0, 1>(acc0, acc1, x, wL1);
         chain_end(acc0, acc1);
         const f4 a1D = lrelu4(acc0 + acc1);
         STAMP(1);
@@ -573,10 +617,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         quad_transpose(x);
         f4 yA, yB;
         {
-            f4 pa0 = splat(bias2a), pa1 = splat(0.f), pb0 = splat(bias2b), pb1 = splat(0.f);
+            f4 pa0 = splat(bias2a), pa1, pb0 = splat(bias2b), pb1;
             chain_begin();
-            chain_a<15, 0>(pa0, pa1, x, wL2A);
-            chain_a<15, 0>(pb0, pb1, x, wL2B);
+            chain_a<15, 0, 1>(pa0, pa1, x, wL2A);
+            chain_a<15, 0, 1>(pb0, pb1, x, wL2B);
             chain_end(pa0, pa1);
             yA = pa0 + pa1;
             yB = pb0 + pb1;
@@ -632,9 +676,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         // quads 1..10 (gyB)
         load_w<8>(wr, w2 + 8 * 64);
         __builtin_amdgcn_sched_barrier(0);
-        acc0 = splat(0.f); acc1 = splat(0.f);
         chain_begin();
-        chain_v<8, 0>(acc0, acc1, gyA, wq);
+        chain_v<8, 0, 2>(acc0, acc1, gyA, wq);
         load_w<10>(ws, w2 + 16 * 64); // (into the registers the first chunk has just released)
         __builtin_amdgcn_sched_barrier(0);
         chain_v<8, 8>(acc0, acc1, gyA, wr);
@@ -643,21 +686,16 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         x = dlrelu4(a1D, acc0 + acc1);
         quad_transpose(x);
         STAMP(6);
-        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0); bL0's weights leave LDS meanwhile
-        f4 wz[10];
-        load_w<10>(wz, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = splat(0.f); acc1 = splat(0.f);
+        // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)
         chain_begin();
-        chain_a<15, 0>(acc0, acc1, x, wB1);
+        chain_a<15, 0, 2>(acc0, acc1, x, wB1);
         chain_end(acc0, acc1);
         x = dlrelu4(a0D, acc0 + acc1);
         quad_transpose(x);
         STAMP(7);
         // ================= bL0 + Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
-        acc0 = splat(0.f); acc1 = splat(0.f);
         chain_begin();
-        chain_v<10, 0>(acc0, acc1, x, wz);
+        chain_v<10, 0, 2>(acc0, acc1, x, wz);
         chain_end(acc0, acc1);
         const f4 g = (acc0 + acc1) + a.ctmp * (zD - ztD);
         STAMP(8);
@@ -701,6 +739,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         STAMP(9);
         if (EARLY && ((unsigned)__ballot(es_act && b == 0) & 0xFu) == 0u) break; // every frame of the wave has stopped
     }
+#ifdef DP_PROFILE
+    prof.t[16] = __builtin_amdgcn_s_memrealtime() - rt0; // 100 MHz ticks over the loop
+    prof.t[17] = __builtin_amdgcn_s_memtime() - mt0;     // shader cycles over the loop
+#endif
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
     if (lane < LAT) {
