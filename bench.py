@@ -9,8 +9,13 @@ iterations per frame) on N MI355X, one process per GPU.
 A "step" is one pass of the hot path (one dp_optimize launch: all 50 iterations of all frames)
 over the rank's batch of synthetic frames (recipe S of SURVEY.md 8d; targets are produced on the
 device with dp_forward).  Inputs are resident in HBM before the timed region.  Frames shard
-across ranks with no data-path collective (weak scaling: --frames per GPU); RCCL is used only
-for the barriers and the final metric reduction.  Rank 0 prints ONE JSON line.
+across ranks with no data-path collective; RCCL is used only for the barriers and the final metric
+reduction.  Rank 0 prints ONE JSON line.
+
+Two ways to size the job:
+  --frames F        F frames PER GPU (default 4096: at N = 1 exactly BASELINE's workload) -> "scaling": "weak"
+  --total-frames T  ONE batch of T frames cut into contiguous shards (dragposer_amd.sharding) -> "scaling": "strong"
+                    (north_star's 4096-frame batch at 1/2/4/8 GPUs: --total-frames 4096; BASELINE config 3: 8192)
 """
 import argparse
 import json
@@ -31,14 +36,17 @@ TRACK6 = [0, 3, 7, 13, 17, 21]
 W6 = {0: (10.0, 10.0), 3: (5.0, 0.01), 7: (5.0, 0.01), 13: (5.0, 0.01), 17: (5.0, 0.01), 21: (5.0, 0.01)}
 
 
-def synth_on_device(opt, B, seed, device):
-    """Recipe S, targets = FK(decode(Zs), CR) computed by the product's own forward kernel."""
+def synth_on_device(opt, B, seed, device, lo=0, hi=None):
+    """Recipe S, targets = FK(decode(Zs), CR) computed by the product's own forward kernel.  [lo, hi): this rank's
+    shard of the B-frame batch (every rank draws the same batch and keeps its rows)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    Zs = torch.randn(B, 24, generator=g) * 0.3
-    Z0 = torch.randn(B, 24, generator=g) * 0.3
-    ZT = Z0 + 0.05 * torch.randn(B, 24, generator=g)
-    CR = torch.randn(B, 4, generator=g)
+    hi = B if hi is None else hi
+    Zs = (torch.randn(B, 24, generator=g) * 0.3)[lo:hi]
+    Z0 = (torch.randn(B, 24, generator=g) * 0.3)[lo:hi]
+    ZT = Z0 + (0.05 * torch.randn(B, 24, generator=g))[lo:hi]
+    CR = torch.randn(B, 4, generator=g)[lo:hi]
     CR = CR / torch.linalg.norm(CR, dim=-1, keepdim=True)
+    B = hi - lo
     w = torch.zeros(B, 22, 2)
     tracked = torch.zeros(B, 22, dtype=torch.uint8)
     for j, wj in W6.items():
@@ -51,11 +59,14 @@ def synth_on_device(opt, B, seed, device):
                 w=w, tracked=tracked)
 
 
+PMC_FILE = "profiles/r02_pmc_per_launch.json"
+
+
 def pmc_traffic_bytes(frames, iters):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_per_launch.json: separate
-    --pmc runs of this very command).  FETCH_SIZE under-counts reads 2x on gfx950 (MI355X_MICROARCH.md, HBM);
-    both counters are in KB.  Only valid for the configuration the counters were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")
+    """HBM bytes per launch, NOT measured in this run: read from the committed rocprofv3 PMC passes of this very command
+    (separate --pmc runs, tools/collect_profiles.sh).  FETCH_SIZE under-counts reads 2x on gfx950
+    (MI355X_MICROARCH.md, HBM); both counters are in KB.  Only valid for the configuration the counters were collected on."""
+    path = os.path.join(ROOT, PMC_FILE)
     if frames != 4096 or iters != 50 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -106,10 +117,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU (weak scaling)")
+    ap.add_argument("--total-frames", type=int, default=0, help="one batch of this many frames sharded over the GPUs (strong scaling)")
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--max-trackers", type=int, default=6,
-                    help="tracker-count bound handed to dp_optimize (the workload has 6); 0 = no hint -> 8-wave kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -139,11 +149,21 @@ def main():
 
     from dragposer_amd.optimizer import LatentOptimizer
 
+    from dragposer_amd.sharding import reduce_stats, shard_bounds
+
     opt = LatentOptimizer(device=device)
-    B, N = args.frames, args.iters
-    batch = synth_on_device(opt, B, 1234 + rank, device)
+    N = args.iters
+    if args.total_frames > 0:  # strong scaling: contiguous shards of ONE batch
+        lo, hi = shard_bounds(args.total_frames, world, rank)
+        if hi <= lo:
+            raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
+        batch = synth_on_device(opt, args.total_frames, 1234, device, lo, hi)
+        B, total_per_step = hi - lo, args.total_frames
+    else:  # weak scaling: every rank its own batch of --frames
+        batch = synth_on_device(opt, args.frames, 1234 + rank, device)
+        B, total_per_step = args.frames, args.frames * world
     names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
-    out = opt.optimize(**batch, n_iter=N, outputs=names, max_trackers=args.max_trackers)
+    out = opt.optimize(**batch, n_iter=N, outputs=names)
     torch.cuda.synchronize()
 
     def barrier():
@@ -151,14 +171,14 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out, max_trackers=args.max_trackers)
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
     barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream the kernel is launched on
     for _ in range(args.steps):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out, max_trackers=args.max_trackers)
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
     ev1.record()
     torch.cuda.synchronize()
     barrier()
@@ -178,15 +198,14 @@ def main():
         e = np.linalg.norm(out["pos"][:nb].cpu().numpy() - ref["pos"], axis=-1) * 1000.0
         err_mm = float(np.percentile(e, 99))
 
-    stats = torch.tensor([dt, kern_ms, err_mm if err_mm == err_mm else -1.0], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)  # the only data collective: 3 doubles over RCCL
-    dt, kern_ms, err_mm = (float(x) for x in stats.cpu())
+    # the only collective of the job: one MAX-reduction of three doubles (RCCL over xGMI; gloo in the rehearsal)
+    (dt, kern_ms, err_mm), _ = reduce_stats(dist, device, max_stats=[dt, kern_ms, err_mm if err_mm == err_mm else -1.0])
 
     if rank == 0:
-        total_frames = B * world * args.steps
-        value = total_frames / dt
-        achieved = B * N * FLOP_PER_FRAME_ITER / (kern_ms * 1e-3)
+        value = total_per_step * args.steps / dt
+        # roofline of the dominant kernel: the slowest rank's launch (the largest shard; its frames set the FLOP count)
+        Bk = -(-total_per_step // world)
+        achieved = Bk * N * FLOP_PER_FRAME_ITER / (kern_ms * 1e-3)
         res = {
             "metric": "frames/sec (6 trackers, 50 iters/frame)",
             "value": value,
@@ -196,20 +215,23 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_frames > 0 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"S1: {B} synthetic frames per GPU, 6 trackers [0,3,7,13,17,21], {N} Adam iters/frame, fp32 "
+            "config": {"workload": (f"S1: ONE batch of {total_per_step} synthetic frames" if args.total_frames > 0 else
+                                    f"S1: {B} synthetic frames per GPU") + f", 6 trackers [0,3,7,13,17,21], {N} Adam iters/frame, fp32 "
                                    f"(BASELINE north_star: 4096-frame batch)",
-                       "frames_per_gpu": B, "iters": N, "parallelism": f"frames sharded x{world}, no data-path collective"},
+                       "frames_per_gpu": Bk, "frames_total": total_per_step, "iters": N,
+                       "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(B, N),
-                         "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch.json; algorithmic 9.53e6",
+                         "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(Bk, N),
+                         "traffic_note": f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes "
+                                         f"({PMC_FILE}, same command); algorithmic {Bk * 2326:.3g}",
                          "kernel": "dp_optimize_kernel<false>" if tpb == 512 else "dp_w4_kernel<4, false>", "kernel_ms": kern_ms,
                          "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},
-                         "flop_per_launch": B * N * FLOP_PER_FRAME_ITER,
-                         "hbm_algorithmic_GBps": B * 1264 / (kern_ms * 1e-3) / 1e9},
+                         "flop_per_launch": Bk * N * FLOP_PER_FRAME_ITER,
+                         "hbm_algorithmic_GBps": Bk * 2326 / (kern_ms * 1e-3) / 1e9},
             "parity_p99_mm_vs_oracle": err_mm,  # 256 frames x 22 joints vs the C oracle (fp32)
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only

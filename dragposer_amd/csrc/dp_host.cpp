@@ -35,6 +35,26 @@ struct dp_ctx {
 
 static thread_local std::string g_create_err;
 
+// Every entry point that touches the device runs on the context's device, whatever the calling thread's current device
+// is, and leaves the caller's current device as it found it (a NULL stream would otherwise launch on the wrong GPU).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+        else prev = -1; // nothing to restore
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define DEVICE_GUARD(ctx)                                                                        \
+    DeviceGuard guard_((ctx)->device);                                                           \
+    if (!guard_.ok) return fail(ctx, DP_ERR_DEVICE, "cannot select the context's device")
+
 static int fail(dp_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->err = msg; else g_create_err = msg;
@@ -434,6 +454,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
 extern "C" int dp_destroy(dp_ctx* ctx)
 {
     if (!ctx) return DP_ERR_INVALID;
+    DeviceGuard guard_(ctx->device);
     hipFree(ctx->d_wfrag);
     hipFree(ctx->d_bias);
     hipFree(ctx->d_items);
@@ -447,7 +468,7 @@ extern "C" int dp_destroy(dp_ctx* ctx)
 extern "C" int dp_io_alloc(dp_ctx* ctx, unsigned long long bytes, void** dev_ptr)
 {
     if (!ctx || !dev_ptr) return DP_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DEVICE_GUARD(ctx);
     HIP_TRY(ctx, hipMalloc(dev_ptr, bytes));
     HIP_TRY(ctx, hipMemset(*dev_ptr, 0, bytes));
     return DP_OK;
@@ -456,6 +477,7 @@ extern "C" int dp_io_alloc(dp_ctx* ctx, unsigned long long bytes, void** dev_ptr
 extern "C" int dp_io_free(dp_ctx* ctx, void* dev_ptr)
 {
     if (!ctx) return DP_ERR_INVALID;
+    DEVICE_GUARD(ctx);
     HIP_TRY(ctx, hipFree(dev_ptr));
     return DP_OK;
 }
@@ -463,6 +485,7 @@ extern "C" int dp_io_free(dp_ctx* ctx, void* dev_ptr)
 extern "C" int dp_io_upload(dp_ctx* ctx, void* dev_dst, const void* host_src, unsigned long long bytes, void* stream)
 {
     if (!ctx || !dev_dst || !host_src) return DP_ERR_INVALID;
+    DEVICE_GUARD(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return DP_OK;
 }
@@ -470,6 +493,7 @@ extern "C" int dp_io_upload(dp_ctx* ctx, void* dev_dst, const void* host_src, un
 extern "C" int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, unsigned long long bytes, void* stream)
 {
     if (!ctx || !host_dst || !dev_src) return DP_ERR_INVALID;
+    DEVICE_GUARD(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return DP_OK;
 }
@@ -477,6 +501,7 @@ extern "C" int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, 
 extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
 {
     if (!ctx) return DP_ERR_INVALID;
+    DEVICE_GUARD(ctx);
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     return DP_OK;
 }
@@ -514,6 +539,7 @@ static void fill_results(const dp_result* out, KArgs& k)
 // 8-wave workgroup) for comparisons; both implement the same operator within the tolerance of tests/test_hip_w4.py.
 static int launch(dp_ctx* ctx, KArgs& k, void* stream)
 {
+    DEVICE_GUARD(ctx);
     const int choice = ctx->forced_kernel == 8 ? 8 : 4;
     ctx->last_kernel = choice;
     hipError_t e = choice == 8 ? dp_launch_optimize(&k, (hipStream_t)stream) : dp_launch_w4(&k, (hipStream_t)stream);
@@ -601,6 +627,7 @@ extern "C" int dp_sequence_advance(dp_ctx* ctx, int n_seq, const dp_result* res,
     a.tgt_pos = step->tgt_pos;
     a.global_pos = st->global_pos; a.global_rot = st->global_rot; a.latent_buf = st->latent_buf; a.disp_buf = st->disp_buf;
     a.heights_buf = st->heights_buf; a.pose_ret = step->pose_ret; a.pos_ret = step->pos_ret;
+    DEVICE_GUARD(ctx);
     hipError_t e = dp_launch_sequence_advance(&a, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("sequence kernel launch: ") + hipGetErrorString(e));
     return DP_OK;

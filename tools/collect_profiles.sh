@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r01/).
+# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r02/).
 # rocprofv3: program directly after `--`; counters in their own passes with --kernel-trace only.
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/prof_r01
+O=gpurun_out/prof_r02
 rm -rf $O && mkdir -p $O
 # 1. kernel-trace stats of the default bench command
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
@@ -18,12 +18,21 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "S
   echo "pmc pass $i done"
 done
 python3 tools/pmc_summary.py $O/pmc_per_launch.json $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 $O/pmc6 $O/pmc7 > /dev/null
-# 3. batch sweep (library's own dispatch, hint 6)
-for fr in 1024 2048 4096 8192 16384 65536; do
+# 3. batch sweep
+for fr in 256 1024 2048 4096 8192 16384 65536; do
   python3 bench.py --frames $fr --steps 20 --warmup 3 --no-cpu-baseline --no-parity | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
 done > $O/batch_sweep.txt
 echo "sweep done"
-# 4. phase stamps (diagnostic build)
-( PWAVE=0 SPECS="4096:0:8 1024:6:4x1 4096:6:4x1 4096:6:4x2 8192:6:4x2" bash tools/phase_profile.sh; echo "---- stamps of wave 4 (second-dispatched half)"; PWAVE=4 SPECS="4096:0:8" bash tools/phase_profile.sh ) > $O/phase_cycles_variants.txt 2>&1
+# 4. phase stamps (diagnostic build): the product's kernel, and the previous decomposition for comparison
+( SPECS="4096:0:w4 1024:0:w4" bash tools/phase_profile.sh; echo "---- previous decomposition (DP_KERNEL=8)"; PWAVE=0 SPECS="4096:0:8" bash tools/phase_profile.sh ) > $O/phase_cycles.txt 2>&1
 echo "phases done"
+# 5. per-launch cost against the iteration count
+python3 tools/time_iters.py 4096 > $O/time_vs_iters.txt 2>&1
+# 6. the N > 1 path rehearsed on this one GPU: two ranks over gloo, both on device 0 (RCCL needs one GPU per rank), weak and
+#    strong sizing; launched through torch.distributed.run exactly as the driver launches the real thing
+for mode in "--frames 4096" "--total-frames 4096" "--total-frames 8192"; do
+  python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 2 \
+      --backend gloo --all-ranks-on-device0 --no-cpu-baseline $mode 2>/dev/null | tail -1
+done > $O/rehearsal_2ranks_gloo_one_gpu.jsonl
+echo "rehearsal done"
 ls $O

@@ -11,7 +11,7 @@ out, dirs = sys.argv[1], sys.argv[2:]
 vals = defaultdict(list)
 for d in dirs:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(path)) if "dp_optimize_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(path)) if "dp_w4_kernel" in r["Kernel_Name"] or "dp_optimize_kernel" in r["Kernel_Name"]]
         if not rows:
             continue
         grid = Counter(r["Grid_Size"] for r in rows).most_common(1)[0][0]
@@ -25,7 +25,7 @@ for d in dirs:
                 vals[k].append(v)
 res = {k: sum(v) / len(v) for k, v in sorted(vals.items())}
 res["_launches_averaged"] = {k: len(v) for k, v in sorted(vals.items())}
-res["_note"] = ("means over the full-size dp_optimize_kernel launches of `bench.py --steps 10 --no-cpu-baseline --no-parity` "
+res["_note"] = ("means over the full-size optimise-kernel launches of `bench.py --steps 10 --no-cpu-baseline --no-parity` "
                 "(4096 frames x 50 iterations); one rocprofv3 --pmc pass per counter group; FETCH_SIZE/WRITE_SIZE in KB as reported "
                 "(FETCH_SIZE under-counts wide reads 2x on gfx950, see MI355X_MICROARCH.md)")
 json.dump(res, open(out, "w"), indent=1)

@@ -33,7 +33,7 @@ grid = (B + fpb - 1) // fpb
 print(f"kernel: {fpb} frames / {tpb} threads per workgroup, {grid} workgroups")
 raw = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20).astype(np.float64) / N
 p = raw[:, :len(NAMES)]
-tot = raw.sum(1)
+tot = p.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:26s} {p[:, i].mean():8.0f}  {100 * p[:, i].mean() / tot.mean():5.1f}%")
