@@ -167,3 +167,44 @@ def test_tracker_counts_beyond_the_fast_paths(opt, opt8, dev, n_trk):
     np.testing.assert_allclose(a["loss"][good], ref["loss"][good], rtol=2e-3, atol=1e-8)
     assert np.isfinite(a["z"]).all() and np.isfinite(a["loss"]).all()
     assert (a["loss"][~has, :2] == 0).all()  # an untracked frame only feels the temporal pull
+
+
+def test_launches_are_graph_capturable(opt, dev, golden_dir):
+    """dp_optimize and dp_sequence_advance allocate nothing and never synchronise: a frame step captured into a HIP graph
+    replays bit for bit (include/dragposer.h: 'graph-capturable'); tools/graph_latency.py times it"""
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    S = 8
+    d = to_device_batch({k: g[k][:S] for k in KEYS}, dev)
+    out = opt.allocate_outputs(S)
+    st = dict(global_pos=torch.zeros(S, 3, device=dev), global_rot=d["cur_rot"].clone(), latent_buf=torch.zeros(S, 60, 24, device=dev),
+              disp_buf=torch.zeros(S, 60, 3, device=dev), heights_buf=torch.zeros(S, 60, 6, device=dev))
+    pose_ret, pos_ret = torch.zeros(S, 88, device=dev), torch.zeros(S, 3, device=dev)
+
+    def step():
+        fr = opt.optimize(**d, n_iter=10, out=out)
+        opt.sequence_advance(fr, st["global_pos"], st["global_rot"], st["latent_buf"], st["disp_buf"], st["heights_buf"],
+                             [0, 4, 8, 13, 17, 21], pose_ret=pose_ret, pos_ret=pos_ret)
+
+    step()
+    torch.cuda.synchronize()
+    want = {k: v.clone() for k, v in out.items()}
+    want_state = {k: v.clone() for k, v in st.items()}
+    want_pose = pose_ret.clone()
+    for v in st.values():
+        v.zero_()
+    st["global_rot"].copy_(d["cur_rot"])
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for v in list(out.values()) + list(st.values()) + [pose_ret]:
+        v.zero_()
+    st["global_rot"].copy_(d["cur_rot"])
+    graph.replay()
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(out[k], want[k]), k
+    for k in want_state:
+        assert torch.equal(st[k], want_state[k]), k
+    assert torch.equal(pose_ret, want_pose)
