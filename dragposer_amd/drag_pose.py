@@ -17,14 +17,54 @@ dimension S (a single sequence may omit it, then the results omit it too, like t
 import numpy as np
 import torch
 
-from .model import NJ
+from .encoder import PoseEncoder
+from .model import DEFAULT_MODEL, NJ
 from .optimizer import LATENT, LatentOptimizer
 from .temporal import HISTORY, PAST_FRAMES, SAMPLE_STEP
 
 
+def arrays_from_generator_model(generator_model, offsets):
+    """The reference's Generator_Model (generator_architecture.py: `.autoencoder`, `.data`, `.parents`) -> the array dict
+    dragposer_amd.model.HostModel / PoseEncoder read (same keys as data/model_dancedb.npz).  `offsets` [22,3] is the
+    skeleton's OFFSET table: the reference hands it to every run() (drag_pose.py:201), the kernel context wants it once."""
+    sd = generator_model.autoencoder.state_dict()
+    arrs = {k: v.detach().cpu().numpy() for k, v in sd.items()}
+    d = generator_model.data
+    arrs["means.dqs"], arrs["stds.dqs"] = d.mean_dqs.detach().cpu().numpy().reshape(-1), d.std_dqs.detach().cpu().numpy().reshape(-1)
+    arrs["means.displacement"] = d.mean_displacement.detach().cpu().numpy().reshape(-1)
+    arrs["stds.displacement"] = d.std_displacement.detach().cpu().numpy().reshape(-1)
+    arrs["parents"] = np.asarray(generator_model.parents, dtype=np.int32)
+    arrs["offsets"] = np.asarray(torch.as_tensor(offsets).detach().cpu(), dtype=np.float32).reshape(NJ, 3)
+    return arrs
+
+
 class DragPose:
-    def __init__(self, optimizer: LatentOptimizer, temporal_model, means_latent, stds_latent, n_sequences=1):
+    def __init__(self, generator_model, temporal_model, means_latent, stds_latent, device=None, device_gpu=None, n_sequences=1,
+                 offsets=None):
+        """Argument order of the reference (drag_pose.py:13).  `generator_model` is one of
+          * a `LatentOptimizer` (an existing kernel context; `device` arguments are then ignored),
+          * None / a path to a model .npz / a dict of its arrays (dragposer_amd.model) -- a context is created on
+            `device_gpu` (or `device` if that names a GPU, else cuda:0),
+          * the reference's own Generator_Model object, with `offsets` [22,3] (see arrays_from_generator_model).
+        `n_sequences`: sequences advancing in lock-step (the reference: 1)."""
+        if isinstance(generator_model, LatentOptimizer) or hasattr(generator_model, "host_model"):
+            optimizer, arrays = generator_model, None
+        else:
+            dev = next((d for d in (device_gpu, device) if d is not None and torch.device(d).type == "cuda"), "cuda:0")
+            if generator_model is None or isinstance(generator_model, str):
+                arrays = None
+                optimizer = LatentOptimizer(model_path=generator_model or DEFAULT_MODEL, device=dev)
+            else:
+                if isinstance(generator_model, dict):
+                    arrays = generator_model
+                else:
+                    if offsets is None:
+                        raise ValueError("a reference Generator_Model carries no bone offsets: pass offsets=[22,3]")
+                    arrays = arrays_from_generator_model(generator_model, offsets)
+                optimizer = LatentOptimizer(device=dev, arrays=arrays)
         self.opt = optimizer
+        self._arrays = arrays
+        self._encoder = None
         self.device = optimizer.device
         self.temporal = temporal_model.to(self.device).eval() if temporal_model is not None else None
         self.S = int(n_sequences)
@@ -53,6 +93,22 @@ class DragPose:
         return self._idx_cache[key]
 
     # ------------------------------------------------------------------ state (drag_pose.py:47-64)
+    def set_initial_pose(self, initial_pose, init_global_pos, initial_global_rot, initial_heights, eps=None, generator=None):
+        """The reference's entry point (drag_pose.py:47): `initial_pose` (S,176,1) normalised dual quaternions ->
+        latent = mu + eps * exp(logvar / 2) through the pose encoder (autoencoder.py:19-27,56-143), then the state of
+        set_initial_state.  `eps` [S,24]: the normal draw to use (the reference takes it from torch's global generator);
+        `generator`: a torch.Generator for the draw otherwise."""
+        S = self.S
+        if self._encoder is None:
+            self._encoder = (PoseEncoder(arrays=self._arrays) if self._arrays is not None else PoseEncoder()).to(self.device)
+        pose = torch.as_tensor(initial_pose, dtype=torch.float32, device=self.device).reshape(S, 176)
+        with torch.no_grad():
+            mu, logvar = self._encoder(pose)
+            if eps is None:
+                eps = torch.randn((S, LATENT), generator=generator)
+            latent = mu + torch.as_tensor(eps, dtype=torch.float32).reshape(S, LATENT).to(self.device) * torch.exp(0.5 * logvar)
+        self.set_initial_state(latent, init_global_pos, initial_global_rot, initial_heights)
+
     def set_initial_state(self, latent, init_global_pos, initial_global_rot, initial_heights):
         """What set_initial_pose leaves behind, with the initial latent given instead of encoded."""
         dev, S = self.device, self.S

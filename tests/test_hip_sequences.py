@@ -163,6 +163,53 @@ def test_eval_drag_cli_on_bvh_clip(tmp_path):
     assert res["mean_iters"] < 60
 
 
+def test_config1_full_example(tmp_path):
+    """BASELINE config 1 at full size: eval_drag on data/example/eval/example.bvh (5052 frames, 120 Hz), 6-tracker config,
+    the reference's early-stop settings (eval_drag.py:210-214), one sequential sequence.  The clip is data of the reference,
+    staged by __graft_entry__.build() into tests/data/_local/ (git-ignored, travels with the snapshot).  lambda_temporal is 0
+    because temporal.pt is missing from the reference mount; accuracy bounds: the paper reports a few cm."""
+    import os
+    import time
+
+    from dragposer_amd import eval_drag
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "data", "_local", "example.bvh")
+    if not os.path.exists(path):
+        pytest.skip("example.bvh not staged (build() copies it where /root/reference is mounted)")
+    t0 = time.time()
+    res = eval_drag.main([path, "--config", os.path.join(root, "dragposer_amd", "config", "6_trackers_config.json"), "--out-dir", str(tmp_path)])[0]
+    wall = time.time() - t0
+    print(f"config 1: {res['frames']} frames, MPJPE {res['mpjpe'] * 1000:.1f} mm, MPEEPE {res['mpeepe'] * 1000:.1f} mm, frame loop {res['time']:.3f} s "
+          f"({res['frames'] / res['time']:.0f} frames/s, {res['mean_iters']:.1f} iterations/frame), whole CLI {wall:.1f} s")
+    assert res["frames"] == 5052 and os.path.exists(res["out"])
+    assert res["mpjpe"] < 0.035 and res["mpeepe"] < 0.040, res  # metres
+    assert res["mean_iters"] < 30
+    assert res["time"] < 5.0  # the reference's CPU loop takes minutes (about 9 frames/s at 50 iterations)
+
+
+def test_reference_constructor_and_set_initial_pose(golden_dir):
+    """the reference's call sequence (eval_drag.py:138,152, run_drag.py:82-96): DragPose(generator_model, temporal_model,
+    means_latent, stds_latent, device, device_gpu); set_initial_pose(initial_pose, init_global_pos, initial_global_rot,
+    initial_heights); run(...)"""
+    import os
+
+    from dragposer_amd.drag_pose import DragPose
+
+    g = np.load(os.path.join(golden_dir, "enc.npz"))
+    dp = DragPose(None, None, np.zeros(24), np.ones(24), "cpu", "cuda:0")  # None: the shipped model_dancedb
+    assert dp.device.type == "cuda" and dp.opt.kernel_geometry()[1] == 256
+    dp.set_initial_pose(g["pose"][3].reshape(1, 176, 1), np.zeros((1, 3, 1), np.float32), np.array([1, 0, 0, 0], np.float32).reshape(1, 4, 1),
+                        g["heights"], eps=g["eps"][3])
+    np.testing.assert_allclose(dp.latent.cpu().numpy()[0], g["latent"][3], atol=5e-5, rtol=1e-5)
+    b = R.synth_inputs(R.OracleModel(), 1)
+    idx = np.array(R.TRACK6)
+    pose, gpos = dp.run(torch.tensor(b["tgt_pos"][0, idx]), torch.tensor(b["tgt_rot"][0, idx]).reshape(6, 3, 3), idx,
+                        np.array([R.W6[j] for j in R.TRACK6], np.float32), max_iter=10, learning_rate=1e-2, lambda_temporal=0.0,
+                        temporal_future_window=0)
+    assert tuple(pose.shape) == (88,) and torch.isfinite(pose).all() and torch.isfinite(gpos).all()
+
+
 def test_eval_drag_lockstep_equals_one_file_at_a_time(tmp_path):
     """--lockstep on a directory: all files advance together (one launch per frame index for all of them) and every
     file gets exactly the result it gets alone, including a file shorter than the others."""

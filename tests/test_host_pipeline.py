@@ -91,3 +91,35 @@ def test_encoder_shapes_and_sampling():
     z = enc.sample(x, generator=g)
     np.testing.assert_allclose(z.numpy(), (mu + torch.randn(3, 24, generator=torch.Generator().manual_seed(0)) * torch.exp(0.5 * lv)).numpy())
     np.testing.assert_allclose(enc.sample(x, use_mean=True).numpy(), mu.numpy())
+
+
+def test_encoder_and_set_initial_pose_match_the_reference(golden_dir):
+    """tests/golden/enc.npz: the REAL Encoder and the REAL DragPose.set_initial_pose (tools/make_goldens.py --only enc) on 24
+    poses, eps recovered from the reference's own draw"""
+    import os
+
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.temporal import HISTORY
+
+    g = np.load(os.path.join(golden_dir, "enc.npz"))
+    enc = PoseEncoder()
+    mu, lv = enc(torch.tensor(g["pose"]))
+    np.testing.assert_allclose(mu.numpy(), g["mu"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(lv.numpy(), g["logvar"], atol=2e-5, rtol=1e-5)
+
+    class _NoKernel:  # the state set-up needs only the device and the model statistics
+        device = torch.device("cpu")
+
+        class host_model:
+            arrays = dict(mean_q=np.zeros(88, np.float32), std_q=np.ones(88, np.float32), offsets=np.zeros((22, 3), np.float32))
+
+    S = len(g["pose"])
+    dp = DragPose(_NoKernel(), None, np.zeros(24), np.ones(24), "cpu", "cpu", n_sequences=S)  # the reference's argument order
+    rot = np.tile(np.array([1, 0, 0, 0], np.float32), (S, 1))
+    dp.set_initial_pose(g["pose"].reshape(S, 176, 1), np.zeros((S, 3, 1), np.float32), rot.reshape(S, 4, 1), np.tile(g["heights"], (S, 1)),
+                        eps=g["eps"])
+    np.testing.assert_allclose(dp.latent.numpy(), g["latent"], atol=5e-5, rtol=1e-5)
+    assert dp.latent_buffer.shape == (S, HISTORY, 24) and dp.heights_buffer.shape == (S, HISTORY, 6)
+    np.testing.assert_allclose(dp.latent_buffer[:, 0].numpy(), g["latent_buffer_row"], atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(dp.heights_buffer[:, 7].numpy(), np.tile(g["heights"], (S, 1)))
+    assert dp.displacement_buffer.abs().max() == 0 and dp.current_index == 0

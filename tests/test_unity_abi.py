@@ -98,7 +98,7 @@ def test_drag_pose_matches_python_operator():
     assert np.abs(z0).max() > 0 and np.isfinite(z0).all()
 
     opt = LatentOptimizer(device="cuda:0")
-    dp = DragPose(opt, None, np.zeros(24), np.ones(24), 1)
+    dp = DragPose(opt, None, np.zeros(24), np.ones(24), n_sequences=1)
     dp.set_initial_state(z0, np.array([0.1, 0.2, 0.3], np.float32), cr0, np.zeros(6))
     idx = np.array(R.TRACK6)
     wj = np.array([R.W6[j] for j in R.TRACK6], np.float32)

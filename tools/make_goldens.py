@@ -7,6 +7,7 @@ product, the tests or the bench; the outputs are data files:
   dragposer_amd/data/model_dancedb.npz   decoder/encoder tensors + dataset statistics + skeleton
                                          (weights are CC BY-SA 4.0, see dragposer_amd/data/NOTICE)
   tests/golden/{s1,s3,s4,es}.npz         inputs and expected outputs of DragPose.run()
+  tests/golden/enc.npz                   the real Encoder and DragPose.set_initial_pose on 24 poses
 
 How the reference is driven (all reference code is executed from /root/reference, nothing is
 copied): the reference modules are imported with tools/pymotion_standin on sys.path (the
@@ -278,6 +279,33 @@ def export_model(parents, offsets):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def encoder_golden(parents):
+    """The real Encoder (autoencoder.py:56-143) and the real DragPose.set_initial_pose (drag_pose.py:47-64) on 24 poses:
+    16 drawn around the dataset mean (normalised space) and 8 far from it.  set_initial_pose draws eps with the global
+    torch RNG (reparameterize, autoencoder.py:19-27): it is seeded per pose and recovered from (latent - mu) / std, so the
+    build can be handed the same eps."""
+    gm, td, drag, stub = build_reference(parents)
+    g = torch.Generator().manual_seed(4321)
+    poses = torch.cat([torch.randn(16, 176, generator=g), 3.0 * torch.randn(8, 176, generator=g)], 0)
+    mus, logvars, latents, epss, bufs = [], [], [], [], []
+    heights = torch.tensor([0.9, 0.1, 0.1, 1.6, 0.8, 0.8])
+    with torch.no_grad():
+        for k in range(len(poses)):
+            x = poses[k].reshape(1, 176, 1)
+            mu, logvar = gm.autoencoder.encoder(x)
+            torch.manual_seed(1000 + k)
+            drag.set_initial_pose(x, torch.zeros(1, 3, 1), torch.tensor([1.0, 0, 0, 0]).reshape(1, 4, 1), heights)
+            lat = drag.latent.detach().reshape(24)
+            mus.append(mu.reshape(24)); logvars.append(logvar.reshape(24)); latents.append(lat)
+            epss.append((lat - mu.reshape(24)) / torch.exp(0.5 * logvar.reshape(24)))
+            assert drag.latent_buffer.shape == (60, 24) and drag.heights_buffer.shape == (60, 6)
+            bufs.append(drag.latent_buffer[0].detach().clone())
+    out = dict(pose=poses.numpy(), mu=torch.stack(mus).numpy(), logvar=torch.stack(logvars).numpy(), latent=torch.stack(latents).numpy(),
+               eps=torch.stack(epss).numpy(), latent_buffer_row=torch.stack(bufs).numpy(), heights=heights.numpy(),
+               meta=json.dumps(dict(seed=4321, eps_seeds="1000 + k", history=60)))
+    return out
+
+
 def anchors(parents, offsets_t):
     """Known-answer anchors A1/A2 of SURVEY.md section 8.1 -> tests/golden/anchors.npz."""
     gm, td, drag, stub = build_reference(parents)
@@ -398,7 +426,7 @@ def run_sequences(name, K, T, cfg, offsets_t, parents, seed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3")
+    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3,enc")
     ap.add_argument("--frames", type=int, default=64)
     args = ap.parse_args()
     todo = args.only.split(",")
@@ -430,6 +458,10 @@ def main():
             path = os.path.join(gold, f"{name}.npz")
             np.savez_compressed(path, **out)
             print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+    if "enc" in todo:
+        path = os.path.join(gold, "enc.npz")
+        np.savez_compressed(path, **encoder_golden(parents))
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
     for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78)):
         if name in todo:
             out = run_sequences(name, K, T, cfg, offsets_t, parents, seed)
