@@ -215,7 +215,13 @@ void load_models(DragPoser* d, char* modelPath)
     m.mean_disp = need("means.displacement"); m.std_disp = need("stds.displacement");
     m.parents = d->parents.data(); m.offsets = d->offsets.data();
     m.weight_dtype = DP_WEIGHTS_FP32;
-    if (d->ctx) { dp_destroy(d->ctx); d->ctx = nullptr; }
+    if (d->ctx) { // loaded before: release the previous context and its device buffers
+        if (d->d_in) dp_io_free(d->ctx, d->d_in);
+        if (d->d_out) dp_io_free(d->ctx, d->d_out);
+        d->d_in = d->d_out = nullptr;
+        dp_destroy(d->ctx);
+        d->ctx = nullptr;
+    }
     if (dp_create(&d->ctx, &m, 0) != DP_OK) { d->fail(std::string("dp_create: ") + dp_last_error(nullptr)); return; }
     if (dp_io_alloc(d->ctx, IN_FLOATS * sizeof(float), &d->d_in) != DP_OK || dp_io_alloc(d->ctx, OUT_FLOATS * sizeof(float), &d->d_out) != DP_OK)
         d->fail(std::string("device buffers: ") + dp_last_error(d->ctx));
@@ -256,9 +262,17 @@ void set_lambdas(DragPoser* d, float lambdaRot, float lambdaTemporal, int tempor
 {
     if (!d) return;
     d->lambda_rot = lambdaRot; d->lambda_tmp = lambdaTemporal; d->window = temporalFutureWindow;
-    if (lambdaTemporal != 0.f && !d->warned_temporal) {
-        d->warned_temporal = true;
-        std::fprintf(stderr, "[DragPoserDLL] no temporal predictor in the native plugin: lambda_temporal is treated as 0\n");
+    d->err.clear();
+    if (lambdaTemporal != 0.f) {
+        // The reference runs its temporal Transformer here (drag_pose.py:234-294).  This plugin has none: the call is
+        // accepted, the pull term stays off, and the difference is REPORTED through drag_poser_last_error (the reference ABI
+        // has no return codes) -- and once on stderr.
+        d->err = "set_lambdas: this build has no temporal predictor; lambdaTemporal = " + std::to_string(lambdaTemporal) +
+                 " is treated as 0 (results differ from the reference's for a non-zero lambda)";
+        if (!d->warned_temporal) {
+            d->warned_temporal = true;
+            std::fprintf(stderr, "[DragPoserDLL] %s\n", d->err.c_str());
+        }
     }
 }
 
@@ -274,7 +288,10 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     d->err.clear();
     if (!d->ctx || !d->initialised) { d->fail("drag_pose: call load_models and init_drag_model first"); return; }
     if (nEE != (int)d->mask_idx.size()) { d->fail("drag_pose: nEndEffectors differs from the tracker mask"); return; }
-    if (d->max_iter < 1 || d->max_iter > 256) { d->fail("drag_pose: maxIter must be in [1, 256]"); return; }
+    if (d->max_iter < 1 || d->max_iter > DP_MAX_ITERS) { // (the reference has no cap; the kernel's per-iteration Adam table has)
+        d->fail("drag_pose: maxIter must be in [1, " + std::to_string(DP_MAX_ITERS) + "]");
+        return;
+    }
     float in[IN_FLOATS];
     std::memset(in, 0, sizeof(in));
     std::memcpy(in + IN_Z0, d->latent, sizeof(d->latent)); // z_tgt stays 0: the pull term is off

@@ -2,13 +2,16 @@
 
 Tolerance (FK joint positions, all 22 joints, millimetres, evaluated at the latent of the last
 forward pass, like the reference's returned pose): max <= 0.05 mm (observed fp32
-re-association noise is ~0.001 mm) on every frame that is WELL-CONDITIONED.  Adam's first steps move
-every latent component by +-lr whatever |g|, so on a few frames a rounding-level sign flip of a
-near-zero gradient component sends the optimisation down another path.  Those frames are a property
-of the data, not of an implementation: they are identified in-test as the frames on which the CPU
-oracle disagrees WITH ITSELF between fp32 and fp64 arithmetic (1 of the 64 frames of the 3-tracker
-fixture, 1-2 of 4096 synthetic 6-tracker frames).  On them the bound is 10 mm plus agreement of
-the final loss; everywhere else it is the strict 0.05 mm.
+re-association noise is ~0.001 mm) on every frame that is WELL-CONDITIONED.  The loss is continuous
+but its gradient is not: the decoder's two LeakyReLU layers switch slope (1 <-> 0.2) where a hidden
+pre-activation crosses zero.  On a frame whose trajectory takes some pre-activation within fp32
+rounding of zero (|pre| of a few 1e-6 or less; typical minimum over 50 iterations: 3e-4), two correct
+implementations pick different slopes for that unit, their gradients differ by O(1) on its path, and
+the optimisation continues down another route.  Those frames are a property of the data, not of an
+implementation: they are identified in-test as the frames on which the CPU oracle disagrees WITH
+ITSELF between fp32 and fp64 arithmetic (1 of the 64 frames of the 3-tracker fixture, 2 of 4096
+synthetic 6-tracker frames), and `_kink_distance` checks the mechanism on them.  On them the bound
+is a few mm plus agreement of the final loss; everywhere else it is the strict 0.05 mm.
 """
 import os
 
@@ -34,6 +37,23 @@ def _sensitive_frames(b, n_iter, lam, weight_rounding="none"):
     o32 = AnalyticOracle(precision="f32", weight_rounding=weight_rounding).optimize(*a, n_iter, lam_tmp=lam)
     o64 = AnalyticOracle(precision="f64", weight_rounding=weight_rounding).optimize(*a, n_iter, lam_tmp=lam)
     return _mm(o32["pos"], o64["pos"]).max(axis=1) > 0.02, o32
+
+
+def _kink_distance(b, frames, n_iter, lam):
+    """smallest |pre-activation| of the two LeakyReLU layers along the fp64 oracle's trajectory of each given frame"""
+    A = AnalyticOracle(precision="f64")
+    F = {k: v.astype(np.float64) for k, v in A.folded().items()}
+    out = []
+    for f in frames:
+        a = [b[k][f:f + 1] for k in KEYS]
+        mk = np.inf
+        for t in range(n_iter):
+            z = (a[0] if t == 0 else A.optimize(*a, t, lam_tmp=lam)["z_final"])[0].astype(np.float64)
+            p0 = F["A0"] @ z + F["c0"]
+            p1 = F["A1"] @ np.maximum(p0, 0.2 * p0) + F["b1"]
+            mk = min(mk, np.abs(p0).min(), np.abs(p1).min())
+        out.append(mk)
+    return np.array(out)
 
 
 @pytest.fixture(scope="module")
@@ -134,7 +154,13 @@ def test_golden_parity_3_trackers_100_iters(opt, golden_dir):
     o = _run(opt, g, mt["n_iter"], mt["lambda_tmp"])
     err = _mm(o["pos"], g["pos"]).max(axis=1)
     sens, _ = _sensitive_frames(g, mt["n_iter"], mt["lambda_tmp"])
-    assert 0 < sens.sum() <= 3  # frame 14 of this fixture: every CPU implementation diverges on it (1.4 - 6.2 mm)
+    kink = _kink_distance(g, np.nonzero(sens)[0], mt["n_iter"], mt["lambda_tmp"])
+    print(f"s3: flagged by the oracle pair {np.nonzero(sens)[0].tolist()} (errors {np.round(err[sens], 3).tolist()} mm, smallest "
+          f"|pre-activation| {kink.tolist()}); largest error elsewhere {err[~sens].max():.4f} mm")
+    # frame 14 of this fixture: every CPU implementation diverges on it (1.4 - 6.2 mm).  Not a LeakyReLU kink here (its
+    # smallest |pre-activation| is 6e-5): with three trackers the legs are unconstrained, the optimum is a flat valley and
+    # 100 Adam steps amplify rounding along it -- the under-constrained path BASELINE config 4 names.
+    assert 0 < sens.sum() <= 3
     assert err[~sens].max() <= 0.05, err[~sens].max()
     assert err[sens].max() <= 10.0, err[sens].max()
     np.testing.assert_allclose(o["z"][~sens], g["z_final"][~sens], atol=5e-4)
@@ -186,15 +212,20 @@ def test_full_size_batch_properties(opt, dev):
     dp = to_device_batch({k: b[k][perm] for k in KEYS}, dev)
     o3 = opt.optimize(**dp, n_iter=50)
     np.testing.assert_array_equal(o3["z"].cpu().numpy(), o1["z"][perm])
-    # Every well-conditioned frame within 0.05 mm of the fp32 oracle.  Ill-conditioned frames (see the module
-    # docstring; measured between CPU oracles on this very batch: 2 of 4096, up to 3.2 mm) plus at most 4
-    # frames that are borderline for the GPU's rounding but not for the CPU's: <= 10 mm.
+    # Every well-conditioned frame within 0.05 mm of the fp32 oracle.  Ill-conditioned frames (module docstring; between
+    # the CPU oracles on this very batch: frames 1657 and 3893, 0.39 and 0.66 mm) plus at most one frame that is
+    # borderline for the GPU's rounding but not for the CPU pair's: <= 5 mm, and every frame that uses the allowance must
+    # show the mechanism -- a LeakyReLU pre-activation within fp32 rounding of zero on its fp64 trajectory.
     sens, ref = _sensitive_frames(b, 50, 0.02)
     err = _mm(o1["pos"], ref["pos"]).max(axis=1)
-    assert sens.sum() <= 8
-    extra = int((err[~sens] > 0.05).sum())
-    assert extra <= 4 and err.max() <= 10.0, (extra, err.max())
-    assert np.percentile(err, 99.8) <= 0.05 and err[~sens].mean() <= 0.002, (np.percentile(err, 99.8), err.mean())
+    allowance = np.nonzero(err > 0.05)[0]
+    extra = [f for f in allowance if not sens[f]]
+    kink = _kink_distance(b, allowance, 50, 0.02)
+    print(f"4096 frames: oracle-flagged {np.nonzero(sens)[0].tolist()}, above 0.05 mm {allowance.tolist()} "
+          f"(errors {np.round(err[allowance], 3).tolist()} mm, smallest |pre-activation| {kink.tolist()}), not flagged by the oracle pair: {extra}")
+    assert sens.sum() <= 4 and len(allowance) <= 4 and len(extra) <= 1 and err.max() <= 5.0, (sens.sum(), allowance, err.max())
+    assert (kink < 5e-6).all(), kink  # typical frames: 1.5e-5 (5 % quantile) ... 3e-4 (median)
+    assert np.percentile(err, 99.8) <= 0.05 and err[err <= 0.05].mean() <= 0.002, (np.percentile(err, 99.8), err.mean())
     first = opt.optimize(**d, n_iter=1)["loss"].cpu().numpy().sum(1)
     assert (o1["loss"].sum(1) < first).mean() > 0.99
     assert np.isfinite(o1["z"]).all()

@@ -88,7 +88,10 @@ def test_drag_pose_matches_python_operator():
         w[j] = wj
     lib.set_mask_and_weights(h, mask.ctypes.data_as(C.POINTER(C.c_float)), w.ctypes.data_as(C.POINTER(F2)))
     lib.set_optim_params(h, 1e-4, 1e-2, 10, 1e-2)  # Unity default budget: 10 iterations (Core/DragPoser.cs:34)
+    lib.set_lambdas(h, 1.0, 0.02, 60)  # what the reference's own debug executable passes (DragPoserDLL/main.cpp)
+    assert b"no temporal predictor" in lib.drag_poser_last_error(h)  # accepted, the gap is reported, the pull term stays off
     lib.set_lambdas(h, 1.0, 0.0, 0)
+    assert lib.drag_poser_last_error(h) == b""
     m = R.OracleModel()
     b = R.synth_inputs(m, 12, seed=5)  # 12 unrelated target frames, fed as a sequence
     cr0 = b["cur_rot"][0]
