@@ -151,6 +151,9 @@ DEV void quad_transpose(f4& r)
 }
 
 DEV f4 splat(float v) { return f4{v, v, v, v}; }
+// LeakyReLU(0.2) as a per-element factor (1 or 0.2): forward a = x * f, backward d = g * f -- the factor is what the
+// backward needs, and both multiplications are packed
+DEV f4 lrelu_factor(f4 x) { return f4{x.x > 0.f ? 1.f : 0.2f, x.y > 0.f ? 1.f : 0.2f, x.z > 0.f ? 1.f : 0.2f, x.w > 0.f ? 1.f : 0.2f}; }
 DEV f2 splat2(float v) { return f2{v, v}; }
 
 // ------------------------------------------------------------------------------------------------
@@ -601,19 +604,19 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         chain_begin();
         chain_a<6, 0, 1>(acc0, acc1, x, wL0);
         chain_end(acc0, acc1);
-        const f4 a0D = lrelu4(acc0 + acc1);
+        const f4 f0D = lrelu_factor(acc0 + acc1); // kept for the backward
         STAMP(0);
         // ================= L1: a1 = lrelu(A1 a0 + b1)
-        x = a0D;
+        x = (acc0 + acc1) * f0D;
         quad_transpose(x);
         acc0 = splat(bias1);
         chain_begin();
         chain_a<10, 0, 1>(acc0, acc1, x, wL1);
         chain_end(acc0, acc1);
-        const f4 a1D = lrelu4(acc0 + acc1);
+        const f4 f1D = lrelu_factor(acc0 + acc1);
         STAMP(1);
         // ================= L2: y = A2 a1 + b2, two 64-row blocks (side A | side B items)
-        x = a1D;
+        x = (acc0 + acc1) * f1D;
         quad_transpose(x);
         f4 yA, yB;
         {
@@ -683,14 +686,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         chain_v<8, 8>(acc0, acc1, gyA, wr);
         chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
         chain_end(acc0, acc1);
-        x = dlrelu4(a1D, acc0 + acc1);
+        x = (acc0 + acc1) * f1D;
         quad_transpose(x);
         STAMP(6);
         // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)
         chain_begin();
         chain_a<15, 0, 2>(acc0, acc1, x, wB1);
         chain_end(acc0, acc1);
-        x = dlrelu4(a0D, acc0 + acc1);
+        x = (acc0 + acc1) * f0D;
         quad_transpose(x);
         STAMP(7);
         // ================= bL0 + Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
