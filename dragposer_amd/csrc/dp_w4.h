@@ -10,7 +10,7 @@
 // Register layouts of a 64-channel x 4-frame tile:
 //     "D" (what a product leaves):   lane 4b+j, register r  = value[channel 4b+j][frame r]
 //     "X" (what a product consumes): lane 4b+i, register m  = value[channel 4b+m][frame i]
-// D <-> X is a 4x4 transpose of (register, lane-in-quad), done with 8 DPP selects, so activations never leave the
+// D <-> X is a 4x4 transpose of (register, lane-in-quad), done with four MFMAs against unit rows, so activations never leave the
 // register file between layers.  X is also the natural layout of the kinematics phase: lane 4b+i holds the 4 channels
 // (one quaternion) of item b of frame i.
 #pragma once

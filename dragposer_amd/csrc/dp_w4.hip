@@ -119,36 +119,27 @@ template <int NG> DEV void load_w(f4 (&wv)[NG], const f4* w)
     static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; wv[g] = w[g * 64]; });
 }
 
-// D <-> X: transpose of (register index, lane-in-quad).  Two exchange stages (lane ^ 1, lane ^ 2), each a select whose
-// first source comes through DPP quad_perm; hipcc does not fold the DPP into the select itself, hence the asm.
-// (VALU write -> DPP read of the same VGPR needs 2 wait states: the leading s_mov + s_nop cover an input written just
-// ahead of the statement; inside, every DPP source is at least two instructions old.)
-DEV void quad_transpose(f4& r)
+// D <-> X: transpose of (register index, lane-in-quad), on the matrix pipe: D_b[i][j] = sum_r x_r[i] * e_r[j] with
+// e_r[j] = (j == r) -- products with 1, sums with 0: exact.  Four dependent 2-pass MFMAs; the result may feed an MFMA
+// (4 wait states) or the VALU (4).  (The VALU form -- two exchange stages of v_cndmask_b32_dpp -- is in
+// tools/ubench/w4_probe.hip; it measured 1.3 % slower in the loop and keeps the VALU busy between two products.)
+DEV void quad_transpose_mfma(f4& r, const f4& e)
 {
-    const unsigned long long even1 = 0x5555555555555555ull, even2 = 0x3333333333333333ull;
-    float n0, n1, n2, n3, m0, m1, m2, m3; // (not volatile: pure functions of their inputs; independent transposes may interleave)
-    asm("s_mov_b64 vcc, %8\n\t"
-                 "s_nop 0\n\t"
-                 "v_cndmask_b32_dpp %0, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %2, %7, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_not_b64 vcc, vcc\n\t"
-                 "v_cndmask_b32_dpp %1, %4, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %3, %6, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
-                 : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "s"(even1)
-                 : "vcc");
-    asm("s_mov_b64 vcc, %8\n\t"
-                 "s_nop 0\n\t"
-                 "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_not_b64 vcc, vcc\n\t"
-                 "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                 : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
-                 : "v"(n0), "v"(n1), "v"(n2), "v"(n3), "s"(even2)
-                 : "vcc");
-    r = f4{m0, m1, m2, m3};
+    f4 d;
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %1, %5, 0\n\t"
+                 "s_nop 1\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0\n\t"
+                 "s_nop 1\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %3, %7, %0\n\t"
+                 "s_nop 1\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
+                 "s_nop 3"
+                 : "=&v"(d)
+                 : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+    r = d;
 }
+#define QT(x) quad_transpose_mfma(x, eT)
 
 DEV f4 splat(float v) { return f4{v, v, v, v}; }
 // LeakyReLU(0.2) as a per-element factor (1 or 0.2): forward a = x * f, backward d = g * f -- the factor is what the
@@ -578,6 +569,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SETUP_STAMP(2);
     wave_sync();
 
+    const f4 eT = {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f, i == 3 ? 1.f : 0.f}; // unit rows of the transposes
     JOut jo;
     Prof prof;
     prof.start();
@@ -599,7 +591,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 
         // ================= L0: a0 = lrelu(A0 z + c0)
         f4 x = zD;
-        quad_transpose(x);
+        QT(x);
         f4 acc0 = splat(bias0), acc1;
         chain_begin();
         chain_a<6, 0, 1>(acc0, acc1, x, wL0);
@@ -608,7 +600,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         STAMP(0);
         // ================= L1: a1 = lrelu(A1 a0 + b1)
         x = (acc0 + acc1) * f0D;
-        quad_transpose(x);
+        QT(x);
         acc0 = splat(bias1);
         chain_begin();
         chain_a<10, 0, 1>(acc0, acc1, x, wL1);
@@ -617,7 +609,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         STAMP(1);
         // ================= L2: y = A2 a1 + b2, two 64-row blocks (side A | side B items)
         x = (acc0 + acc1) * f1D;
-        quad_transpose(x);
+        QT(x);
         f4 yA, yB;
         {
             f4 pa0 = splat(bias2a), pa1, pb0 = splat(bias2b), pb1;
@@ -628,8 +620,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             yA = pa0 + pa1;
             yB = pb0 + pb1;
         }
-        quad_transpose(yA); // lane (b, i): the decoder quads of my two items of frame i
-        quad_transpose(yB);
+        QT(yA); // lane (b, i): the decoder quads of my two items of frame i
+        QT(yB);
         STAMP(2);
 
         // ================= kinematics
@@ -687,14 +679,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
         chain_end(acc0, acc1);
         x = (acc0 + acc1) * f1D;
-        quad_transpose(x);
+        QT(x);
         STAMP(6);
         // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)
         chain_begin();
         chain_a<15, 0, 2>(acc0, acc1, x, wB1);
         chain_end(acc0, acc1);
         x = (acc0 + acc1) * f0D;
-        quad_transpose(x);
+        QT(x);
         STAMP(7);
         // ================= bL0 + Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
         chain_begin();
