@@ -272,8 +272,9 @@ extern "C" int dp_debug_pack_w4(const dp_folded* f, const dp_model* m, float* im
         return r >= 0 ? (double)m->mean_q[r] : (c == 0 ? 1.0 : 0.0); // idle rows decode to the unit quaternion
     };
     for (int l = 0; l < 64; ++l) {
-        for (int k = 0; k < 24; ++k) put(dpw4::S_L0 + k, l, l < 40 ? f->A0[l * 24 + k] : 0.f);
-        for (int k = 0; k < 40; ++k) put(dpw4::S_L1 + k, l, l < 60 ? f->A1[l * 40 + k] : 0.f);
+        const int c0ch = dpw4::h0_channel(l); // the first hidden layer's channel in row l (dp_w4.h), or -1
+        for (int k = 0; k < 24; ++k) put(dpw4::S_L0 + k, l, c0ch >= 0 ? f->A0[c0ch * 24 + k] : 0.f);
+        for (int k = 0; k < 40; ++k) put(dpw4::S_L1 + k, l, l < 60 ? f->A1[l * 40 + k] : 0.f); // (K-step k = channel k: quads 0..4, 8..12)
         const int ia = dpw4::item_of(0, l >> 2), ib = dpw4::item_of(1, l >> 2), c = l & 3;
         const int ra = w4_src_row(pl, ia, c), rb = ib >= 0 ? w4_src_row(pl, ib, c) : -1;
         for (int k = 0; k < 60; ++k) {
@@ -285,9 +286,10 @@ extern "C" int dp_debug_pack_w4(const dp_folded* f, const dp_model* m, float* im
             const int r = w4_src_row(pl, item, k & 3);
             put(dpw4::S_B2 + k, l, (l < 60 && r >= 0) ? (float)(sd_of(item, k & 3) * (double)f->A2[r * 60 + l]) : 0.f);
         }
-        for (int k = 0; k < 60; ++k) put(dpw4::S_B1 + k, l, l < 40 ? f->A1[k * 40 + l] : 0.f);
-        for (int k = 0; k < 40; ++k) put(dpw4::S_B0 + k, l, l < 24 ? f->A0[k * 24 + l] : 0.f);
-        bias[l] = l < 40 ? f->c0[l] : 0.f;
+        for (int k = 0; k < 60; ++k) put(dpw4::S_B1 + k, l, c0ch >= 0 ? f->A1[k * 40 + c0ch] : 0.f);
+        for (int k = 0; k < 20; ++k) // bL0, K split: lanes 0..31 carry K-step k, lanes 32..63 K-step 20 + k, of rows l & 31
+            put(dpw4::S_B0 + k, l, (l & 31) < 24 ? f->A0[((l < 32 ? 0 : 20) + k) * 24 + (l & 31)] : 0.f);
+        bias[l] = c0ch >= 0 ? f->c0[c0ch] : 0.f;
         bias[64 + l] = l < 60 ? f->b1[l] : 0.f;
         bias[128 + l] = (float)(sd_of(ia, c) * (ra >= 0 ? (double)f->b2[ra] : 0.0) + mu_of(ia, c));
         bias[192 + l] = ib >= 0 ? (float)(sd_of(ib, c) * (rb >= 0 ? (double)f->b2[rb] : 0.0) + mu_of(ib, c)) : (c == 0 ? 1.f : 0.f);

@@ -6,6 +6,8 @@
 //     D_b[i][j] += A_ABID[i] * B_b[j]          lane 4b+j, register i   (b = block, probe: tools/ubench/w4_probe.hip)
 // is a rank-1 update of a (64 output channels) x (4 frames) tile:  i = frame, 4b+j = output channel,
 //     A = activations, ONE register holds 16 K-steps: lane 4b+i = act[frame i][channel k(b)]
+//         (CBSZ = 3: blocks 0..7 take block ABID, blocks 8..15 block 8 + ABID -- two K-steps per instruction for products of
+//          at most 32 rows, used by bL0)
 //     B = weights of K-step k: lane l = W[row l][k]   (streamed from LDS, one ds_read_b128 per 4 steps)
 // Register layouts of a 64-channel x 4-frame tile:
 //     "D" (what a product leaves):   lane 4b+j, register r  = value[channel 4b+j][frame r]
@@ -27,13 +29,21 @@ constexpr int S_L2A = S_L1 + 40;   // 60: rows = side-A items of y (4 channels e
 constexpr int S_L2B = S_L2A + 60;  // 60: rows = side-B items of y
 constexpr int S_B2 = S_L2B + 60;   // 104: K = 4 channels of the 16 side-A items, then of side-B quads 1..10; rows = 60 channels of d1
 constexpr int S_B1 = S_B2 + 104;   // 60: rows = 40 channels of d0
-constexpr int S_B0 = S_B1 + 60;    // 40: rows = 24 channels of dL/dz
-constexpr int N_STEPS = S_B0 + 40; // 388
+constexpr int S_B0 = S_B1 + 60;    // 20: rows = 24 channels of dL/dz, K split over the two lane halves (below)
+constexpr int N_STEPS = S_B0 + 20; // 368
 constexpr int N_GROUPS = N_STEPS / 4;
 // device image: [group][lane][4 steps] floats  (a lane's four steps are one ds_read_b128)
 constexpr int IMG_FLOATS = N_GROUPS * 64 * 4;
 // bias image [4][64]: L0, L1, L2A, L2B rows (the accumulators start from it)
 constexpr int BIAS_FLOATS = 4 * 64;
+
+// The 40 channels of the first hidden layer sit in rows (= lanes of layout D, = quads of layout X) 0..19 and 32..51:
+// channel c < 20 in row c, channel c >= 20 in row 12 + c.  That puts one half of them in quads 0..4 and the other in
+// quads 8..12, which is what lets bL0 (24 output rows: half a register of weights per K-step) run TWO K-steps per
+// instruction: with CBSZ = 3, blocks 0..7 take their A operand from quad ABID and blocks 8..15 from quad 8 + ABID, so lanes
+// 0..31 accumulate K-steps 0..19 and lanes 32..63 K-steps 20..39 of the same rows; one half-wave swap adds them.
+DP_HD constexpr int h0_row(int c) { return c < 20 ? c : 12 + c; }
+DP_HD constexpr int h0_channel(int row) { return row < 20 ? row : (row >= 32 && row < 52 ? row - 12 : -1); }
 
 // Kinematics items of a lane quad b: side A = item b (the 16 joints 0..15), side B = item 15 + b for b = 1..10 (joints
 // 16..21, the root displacement 22, virtual child-bone copies 23..25); quad 0's side B is idle, so that the root (side A

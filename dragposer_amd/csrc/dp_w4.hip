@@ -75,6 +75,18 @@ template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE
                  "s_nop 0"                                                                                                \
                  : "+v"(acc0), "+v"(acc1)                                                                                 \
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
+// the same with CBSZ = 3 (two K-steps per instruction, dp_w4.h), weights in vector registers, starting from zero or not
+#define W4_GROUP3_ASM(C0, C1, OUT)                                                                                        \
+    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, " C0 " cbsz:3 abid:%10\n\t"                                       \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, " C1 " cbsz:3 abid:%10\n\t"                                       \
+                 "s_nop 0\n\t"                                                                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:3 abid:%10\n\t"                                           \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:3 abid:%10\n\t"                                           \
+                 "s_nop 0"                                                                                                \
+                 : OUT(acc0), OUT(acc1)                                                                                   \
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(ABID))
+template <int ABID> DEV void group3_v(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP3_ASM("%0", "%1", "+v"); }
+template <int ABID> DEV void first3_v_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP3_ASM("0", "0", "=&v"); }
 template <int ABID> DEV void group_a(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP_ASM("a"); }
 template <int ABID> DEV void group_v(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP_ASM("v"); }
 // first group of a chain: the accumulators START here -- acc1 (and acc0, when the product has no bias row) take the inline
@@ -113,6 +125,23 @@ template <int NG, int ABID0, int START = 0> DEV void chain_v(f4& acc0, f4& acc1,
         if constexpr (g == 0 && START == 2) first_v_zero<ABID0>(acc0, acc1, x, wv[0]);
         else group_v<ABID0 + g>(acc0, acc1, x, wv[g]);
     });
+}
+template <int NG> DEV void chain3_v_zero(f4& acc0, f4& acc1, const f4& x, const f4* wv)
+{ // NG groups of 2 x 4 K-steps from zero: quads 0..NG-1 against lanes 0..31, quads 8..8+NG-1 against lanes 32..63
+    static_for<NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (g == 0) first3_v_zero<0>(acc0, acc1, x, wv[0]);
+        else group3_v<g>(acc0, acc1, x, wv[g]);
+    });
+}
+DEV f4 add_halves(f4 v)
+{ // lanes l and l ^ 32 both get v[l] + v[l ^ 32] (one v_permlane32_swap + one add per register)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[r]), __float_as_uint(v[r]), false, false);
+        v[r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    return v;
 }
 template <int NG> DEV void load_w(f4 (&wv)[NG], const f4* w)
 {
@@ -473,8 +502,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         load_w<15>(wL2B, w + (S_L2B / 4) * 64);
         load_w<15>(wB1, w + (S_B1 / 4) * 64);
     }
-    f4 wz[10]; // bL0's weights: resident too, in VECTOR registers (measured +2 % over streaming them; the accumulator half is full)
-    load_w<10>(wz, (const f4*)a.w4img + lane + (S_B0 / 4) * 64);
+    f4 wz[5]; // bL0's weights: resident too, in VECTOR registers (measured +2 % over streaming them; the accumulator half is full)
+    load_w<5>(wz, (const f4*)a.w4img + lane + (S_B0 / 4) * 64);
 
     // ---- the streamed weight image into LDS (the only data the waves of a workgroup share)
     for (int k = tid; k < NG_B2 * 64; k += NW * 64) ((f4*)(lds + L_IMG2))[k] = ((const f4*)a.w4img)[GR_B2 * 64 + k];
@@ -603,7 +632,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         QT(x);
         acc0 = splat(bias1);
         chain_begin();
-        chain_a<10, 0, 1>(acc0, acc1, x, wL1);
+        chain_a<5, 0, 1>(acc0, acc1, x, wL1);   // the hidden layer's channels 0..19: quads 0..4,
+        chain_a<5, 8>(acc0, acc1, x, wL1 + 5);  // 20..39: quads 8..12 (dp_w4.h)
         chain_end(acc0, acc1);
         const f4 f1D = lrelu_factor(acc0 + acc1);
         STAMP(1);
@@ -690,9 +720,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         STAMP(7);
         // ================= bL0 + Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
         chain_begin();
-        chain_v<10, 0, 2>(acc0, acc1, x, wz);
+        chain3_v_zero<5>(acc0, acc1, x, wz); // two K-steps per instruction: lanes 0..31 | 32..63 hold the two halves of the sum
         chain_end(acc0, acc1);
-        const f4 g = (acc0 + acc1) + a.ctmp * (zD - ztD);
+        const f4 g = add_halves(acc0 + acc1) + a.ctmp * (zD - ztD);
         STAMP(8);
         if (DBG_DUMP && a.dbg && iter == 0 && lane < LAT) {
 #pragma unroll

@@ -24,14 +24,16 @@ def test_weight_image_is_the_folded_decoder(tables):
     f, _ = HostModel().fold()
     rs = np.random.RandomState(0)
     x = rs.randn(24)
-    np.testing.assert_allclose(W.product(img, W.S_L0, x)[:40], f["A0"].astype(np.float64) @ x, rtol=1e-12, atol=1e-12)
-    assert not W.product(img, W.S_L0, x)[40:].any() and not bias[0][40:].any()
+    np.testing.assert_allclose(W.product(img, W.S_L0, x)[W.H0_ROW], f["A0"].astype(np.float64) @ x, rtol=1e-12, atol=1e-12)
+    unused = np.setdiff1d(np.arange(64), W.H0_ROW)
+    assert not W.product(img, W.S_L0, x)[unused].any() and not bias[0][unused].any()
     x = rs.randn(40)
     np.testing.assert_allclose(W.product(img, W.S_L1, x)[:60], f["A1"].astype(np.float64) @ x, rtol=1e-12, atol=1e-12)
     x = rs.randn(60)
-    np.testing.assert_allclose(W.product(img, W.S_B1, x)[:40], f["A1"].astype(np.float64).T @ x, rtol=1e-12, atol=1e-12)
-    x = rs.randn(40)
-    np.testing.assert_allclose(W.product(img, W.S_B0, x)[:24], f["A0"].astype(np.float64).T @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(W.product(img, W.S_B1, x)[W.H0_ROW], f["A1"].astype(np.float64).T @ x, rtol=1e-12, atol=1e-12)
+    x = rs.randn(40)  # bL0: lanes 0..31 hold K-steps 0..19, lanes 32..63 K-steps 20..39 of the same 24 rows
+    lo, hi = W.product(img, W.S_B0, x[:20]), W.product(img, W.S_B0, x[20:])
+    np.testing.assert_allclose((lo[:32] + hi[32:])[:24], f["A0"].astype(np.float64).T @ x, rtol=1e-12, atol=1e-12)
     # layer 2 carries the de-normalisation: rows of sigma * A2, bias sigma * b2 + mu, per item of a quad's two sides
     hm = HostModel()
     x = rs.randn(60)

@@ -9,7 +9,8 @@ import numpy as np
 
 from dragposer_amd import _lib
 
-S_L0, S_L1, S_L2A, S_L2B, S_B2, S_B1, S_B0, N_STEPS = 0, 24, 64, 124, 184, 288, 348, 388
+S_L0, S_L1, S_L2A, S_L2B, S_B2, S_B1, S_B0, N_STEPS = 0, 24, 64, 124, 184, 288, 348, 368
+H0_ROW = np.array([c if c < 20 else 12 + c for c in range(40)])  # dp_w4.h: row (lane of layout D) of the first hidden layer's channel c
 KIND_JOINT, KIND_ROOT, KIND_DISP, KIND_VIRT, KIND_IDLE = 0, 1, 2, 3, 4
 PAIR = np.dtype([("sd", "<f4", (4, 2)), ("mu", "<f4", (4, 2)), ("off", "<f4", (3, 2)), ("sgn", "<f4", 2), ("rho", "<f4", 2),
                  ("item", "<i4", 2), ("kind", "<i4", 2), ("bone_slot", "<i4", 2), ("ch_sub", "<u4", 2), ("pad", "<i4", 2)])
@@ -89,7 +90,7 @@ def one_iteration(tables, z, z_tgt, cur, tgt_pos, tgt_rot, w, tracked, lam_rot=1
     img, bias, pairs, items = tables
     z = np.asarray(z, np.float64)
     # ---- decoder forward (accumulators start from the bias rows; L2 leaves DE-NORMALISED channels)
-    a0 = lrelu(product(img, S_L0, z) + bias[0])[:40]
+    a0 = lrelu(product(img, S_L0, z) + bias[0])[H0_ROW]
     a1 = lrelu(product(img, S_L1, a0) + bias[1])[:60]
     rq = {0: (product(img, S_L2A, a1) + bias[2]).reshape(16, 4), 1: (product(img, S_L2B, a1) + bias[3]).reshape(16, 4)}
     # ---- stage J
@@ -150,7 +151,13 @@ def one_iteration(tables, z, z_tgt, cur, tgt_pos, tgt_rot, w, tracked, lam_rot=1
     # ---- decoder backward: K = channels of the 16 side-A items, then of side-B quads 1..10
     gyk = np.concatenate([gy[0].reshape(64), gy[1][1:11].reshape(40)])
     d1 = product(img, S_B2, gyk)[:60] * np.where(a1 > 0, 1.0, 0.2)
-    d0 = product(img, S_B1, d1)[:40] * np.where(a0 > 0, 1.0, 0.2)
-    gz = product(img, S_B0, d0)[:24] + 2.0 * lam_tmp / 24.0 * (z - z_tgt)
+    d0 = product(img, S_B1, d1)[H0_ROW] * np.where(a0 > 0, 1.0, 0.2)
+    # bL0 runs two K-steps per instruction: lanes 0..31 against channels 0..19, lanes 32..63 against channels 20..39
+    half = np.zeros(64)
+    for k in range(20):
+        w = step_rows(img, S_B0 + k)
+        half[:32] += w[:32] * d0[k]
+        half[32:] += w[32:] * d0[20 + k]
+    gz = (half[:32] + half[32:])[:24] + 2.0 * lam_tmp / 24.0 * (z - z_tgt)
     lt = lam_tmp * np.mean((z - z_tgt) ** 2)
     return (lp, lr, lt), gz, QS, BN
