@@ -229,40 +229,69 @@ DEV Q4 quat_from_rotmat(const float* m)
     return {q.w * n, q.x * n, q.y * n, q.z * n};
 }
 
-// tracker of rank `rank` of the frame whose tracked-joint mask is `tmask` (E of them): inputs from global memory, rotated
-// into the frame of `cur`, stored in the frame block (general path, epilogue) and returned
-DEV TRec make_tracker(const KArgs& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur)
-{
-    TRec t;
-    t.act = rank < E;
-    t.rank = rank;
+// tracker of rank `rank` of the frame whose tracked-joint mask is `tmask` (E of them), in two halves so that the setup can
+// have the inputs in flight while other loads are issued: tracker_fetch issues the global loads, tracker_finish rotates the
+// targets into the frame of `cur`, stores the record in the frame block (general path, epilogue) and returns it
+struct TRaw {
+    bool act;
+    int rank, j;
+    unsigned plo, phi;
+    float p[3], wp, wr, m[9];
+};
+DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, int E, int rank)
+{ // (!optimise: no tracker arrays -- E = 0, every lane inactive; the loads read the weight image instead and are ignored)
+    TRaw r;
+    r.act = rank < E;
+    r.rank = rank;
     unsigned m = tmask;
     for (int u = 0; u < rank; ++u) m &= m - 1u;
-    const int j = t.act ? __builtin_ctz(m | 0x80000000u) : 0;
+    const int j = r.act ? __builtin_ctz(m | 0x80000000u) : 0;
+    r.j = j;
+    r.plo = a.items[j].path_lo;
+    r.phi = a.items[j].path_hi;
+    const int row = optimise ? gf * NJ + j : 0; // (inactive lanes read joint 0's inputs and ignore them)
+    const float* p = (optimise ? a.tgt_pos : a.w4img) + (size_t)row * 3;
+    const float* rm = (optimise ? a.tgt_rot : a.w4img) + (size_t)row * 9;
+    const float* wv = (optimise ? a.w : a.w4img) + (size_t)row * 2;
+    r.p[0] = p[0]; r.p[1] = p[1]; r.p[2] = p[2];
+    r.wp = wv[0];
+    r.wr = wv[1];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.m[k] = rm[k];
+    return r;
+}
+DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur)
+{
+    TRec t;
+    t.act = r.act;
+    t.rank = r.rank;
+    const int j = r.j;
     t.qs = FB_QS + 4 * (j == 0 ? QS_IDENT : j); // the root is the identity in its own frame
     t.wt = FB_WT + 4 * (j == 0 ? WT_TRASH : j); // ... and has no torque of its own: everything goes to the root sum
-    t.plo = a.items[j].path_lo;
-    t.phi = a.items[j].path_hi;
+    t.plo = r.plo;
+    t.phi = r.phi;
     t.tp = {0.f, 0.f, 0.f};
     t.qT = {1.f, 0.f, 0.f, 0.f};
     t.cgp = t.clp = t.k8 = t.clr8 = 0.f;
     if (t.act) {
         const float invE = 1.f / (float)E;
-        const float* p = a.tgt_pos + (size_t)(gf * NJ + j) * 3;
-        const float wp = a.w[(gf * NJ + j) * 2 + 0], wr = a.w[(gf * NJ + j) * 2 + 1];
-        t.tp = rot_conj(cur, V3{p[0], p[1], p[2]});
-        t.qT = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, quat_from_rotmat(a.tgt_rot + (size_t)(gf * NJ + j) * 9));
-        t.clp = wp * invE * (1.f / 3.f);                       // loss_pos coefficient  w_pos / (3E)
-        const float clr = a.lam_rot * wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
+        t.tp = rot_conj(cur, V3{r.p[0], r.p[1], r.p[2]});
+        t.qT = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, quat_from_rotmat(r.m));
+        t.clp = r.wp * invE * (1.f / 3.f);                       // loss_pos coefficient  w_pos / (3E)
+        const float clr = a.lam_rot * r.wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
         t.cgp = 2.f * t.clp;
         t.k8 = -8.f * clr;
         t.clr8 = 8.f * clr;
-        float* ti = fb + FB_TI + rank * 4;
+        float* ti = fb + FB_TI + r.rank * 4;
         *(f4*)(ti) = f4{t.tp.x, t.tp.y, t.tp.z, t.cgp};
         *(f4*)(ti + 4 * W4_R) = f4{t.qT.w, t.qT.x, t.qT.y, t.qT.z};
         *(f4*)(ti + 8 * W4_R) = f4{t.k8, t.clp, t.clr8, __int_as_float(j)};
     }
     return t;
+}
+DEV TRec make_tracker(const KArgs& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur)
+{
+    return tracker_finish(a, fb, tracker_fetch(a, true, gf, tmask, E, rank), E, cur);
 }
 
 DEV TRec load_tracker(const KArgs& a, const float* fb, int E, int rank)
@@ -403,12 +432,25 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
 
 // ---- outputs of the LAST forward pass of (item, frame gf) from the frame block (reference: drag_pose.py:84-113 and what
 // run() returns); kept simple, it runs once
-DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
+struct OutC { int item, kind; f4 sd, mu; unsigned plo, phi; }; // what an item's outputs need from global memory
+DEV void out_consts(const KArgs& a, const Pair* pp, int itemA, int kindA, int itemB, int kindB, OutC& oA, OutC& oB)
+{ // every load of the epilogue, issued together (one round trip instead of one per item and table)
+    const f4* t = (const f4*)pp; // sd[4][2], mu[4][2]: the two sides interleaved
+    const f4 s0 = t[0], s1 = t[1], m0 = t[2], m1 = t[3];
+    oA.item = itemA; oA.kind = kindA;
+    oB.item = itemB; oB.kind = kindB;
+    oA.sd = f4{s0.x, s0.z, s1.x, s1.z}; oB.sd = f4{s0.y, s0.w, s1.y, s1.w};
+    oA.mu = f4{m0.x, m0.z, m1.x, m1.z}; oB.mu = f4{m0.y, m0.w, m1.y, m1.w};
+    const ItemConst* ia = a.items + max(itemA, 0);
+    const ItemConst* ib = a.items + max(itemB, 0);
+    oA.plo = ia->path_lo; oA.phi = ia->path_hi;
+    oB.plo = ib->path_lo; oB.phi = ib->path_hi;
+}
+DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
 {
-    const int item = pp->item[side], kind = pp->kind[side];
+    const int item = oc.item, kind = oc.kind;
     if (item < 0 || kind == KIND_IDLE || kind == KIND_VIRT) return;
-    const f4 sd = {pp->sd[0][side], pp->sd[1][side], pp->sd[2][side], pp->sd[3][side]};
-    const f4 mu = {pp->mu[0][side], pp->mu[1][side], pp->mu[2][side], pp->mu[3][side]};
+    const f4 sd = oc.sd, mu = oc.mu;
     const f4 qv = *(const f4*)(fb + FB_QS + 4 * item); // what stage J of the last forward pass left: unit quaternion / displacement
     const Q4 rq = {qv.x, qv.y, qv.z, qv.w};
     const f4 q0v = *(const f4*)(fb + FB_QS);
@@ -430,7 +472,7 @@ DEV void w4_outputs(const KArgs& a, const Pair* pp, int side, const float* fb, i
     if (a.pos) {
         const f4 dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
         V3 pr = {dv.x, dv.y, dv.z};
-        const unsigned plo = a.items[item].path_lo, phi = a.items[item].path_hi;
+        const unsigned plo = oc.plo, phi = oc.phi;
         f4 bn[MAX_PATH];
 #pragma unroll
         for (int k = 0; k < MAX_PATH; ++k) bn[k] = *(const f4*)(fb + FB_BN + 4 * ((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)));
@@ -479,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #ifdef DP_PROFILE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
     unsigned long long t_setup[5] = {0, 0, 0, 0, 0};
-#define SETUP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t_setup[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SETUP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); t_setup[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0) // (no drain: when the wave gets here)
 #else
 #define SETUP_STAMP(i)
 #endif
@@ -491,43 +533,28 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const int f0 = (blockIdx.x * NW + wave) * FPW;
     const bool optimise = (a.mode == 0);
 
-    // ---- resident weight images first: 71 loads per lane from the (L2-resident) global image, in flight while the rest of
-    //      the setup runs.  (MFMA B operands, loop-invariant: L0, L1, L2A, L2B, bL1 = 61 groups = 244 accumulator registers)
-    f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15];
-    {
-        const f4* w = (const f4*)a.w4img + lane;
-        load_w<6>(wL0, w + (S_L0 / 4) * 64);
-        load_w<10>(wL1, w + (S_L1 / 4) * 64);
-        load_w<15>(wL2A, w + (S_L2A / 4) * 64);
-        load_w<15>(wL2B, w + (S_L2B / 4) * 64);
-        load_w<15>(wB1, w + (S_B1 / 4) * 64);
-    }
-    f4 wz[5]; // bL0's weights: resident too, in VECTOR registers (measured +2 % over streaming them; the accumulator half is full)
-    load_w<5>(wz, (const f4*)a.w4img + lane + (S_B0 / 4) * 64);
-
-    // ---- the streamed weight image into LDS (the only data the waves of a workgroup share)
-    for (int k = tid; k < NG_B2 * 64; k += NW * 64) ((f4*)(lds + L_IMG2))[k] = ((const f4*)a.w4img)[GR_B2 * 64 + k];
-    for (int k = tid; k < a.n_iter; k += NW * 64) *(f2*)(lds + L_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]};
-    float* fb0 = lds + L_FR + wave * FPW * FB_STRIDE; // this wave's four frame blocks
-    // what has to read as zero in a frame block: the own-torque slots of untracked joints, the two tracker tables (stage G
-    // reads rows beyond a frame's tracker count) and the bones' zero slot
-    constexpr int NZ = 32 + 2 * W4_R + 1;
-    for (int k = lane; k < FPW * NZ; k += 64) {
-        const int fr = k / NZ, r = k % NZ;
-        *(f4*)(fb0 + fr * FB_STRIDE + (r < 32 ? FB_WT + 4 * r : r < 32 + 2 * W4_R ? FB_GP + 4 * (r - 32) : FB_BN + 4 * SLOT_ZERO)) = f4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    SETUP_STAMP(0);
-    if (f0 >= nB) return; // (uniform per wave) no barrier below this line
-
     const int gfi = min(f0 + i, nB - 1); // my frame as the lane of a quad (clamped: ragged tails compute a copy)
     const bool fvalid = f0 + i < nB;
+    float* fb0 = lds + L_FR + wave * FPW * FB_STRIDE; // this wave's four frame blocks
     float* fb = fb0 + i * FB_STRIDE;
 
-    // ---- per-lane accumulator seeds (bias rows of L0, L1, L2A, L2B)
+    // ---- The setup is a chain of dependent global round trips (tracked flags -> which joints -> their targets) beside one
+    //      long stream (the resident weights, 73 KB per wave).  Loads of a wave complete in issue order and issuing blocks
+    //      once the memory pipeline is full, so the order of ISSUE below is: the small first-level loads; half of the
+    //      stream (the first level comes back while it drains); the trackers' second-level loads; the other half (the
+    //      second level comes back under it); then the arithmetic on what has arrived.
+    // (dp_forward has no trackers and passes no tracker arrays: the loads then read the weight image and are ignored)
+    typedef unsigned u32_any __attribute__((aligned(1), may_alias));
+    typedef unsigned short u16_any __attribute__((aligned(1), may_alias));
+    const unsigned char* trow = optimise ? a.tracked + (size_t)gfi * NJ : (const unsigned char*)a.w4img;
+    unsigned tflag[6]; // the 22 flags of my frame: five unaligned words and a half
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tflag[k] = ((const u32_any*)trow)[k];
+    tflag[5] = *(const u16_any*)(trow + 20);
+    const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
+    // per-lane accumulator seeds (bias rows of L0, L1, L2A, L2B)
     const float bias0 = a.w4bias[lane], bias1 = a.w4bias[64 + lane], bias2a = a.w4bias[128 + lane], bias2b = a.w4bias[192 + lane];
-
-    // ---- latent and Adam state in the D layout of the last product: lane = latent dim, register r = frame f0 + r
+    // latent and Adam state in the D layout of the last product: lane = latent dim, register r = frame f0 + r
     f4 zD = {0.f, 0.f, 0.f, 0.f}, ztD = zD, mD = zD, vD = zD;
     if (lane < LAT) {
 #pragma unroll
@@ -537,17 +564,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             if (optimise) ztD[r] = a.z_tgt[(size_t)gf * LAT + lane];
         }
     }
-
-    f4 zfinD = zD;               // early stop: latent after a frame's last step
-    float es_prev = 10000000.f;  // early stop, lanes 0..3 (quad 0 = the root's) = frames: previous total loss (drag_pose.py:297),
-    bool es_act = true;          //   still iterating,
-    int es_iters = 0;            //   iterations executed
-    if (EARLY && lane < LAT) {
-#pragma unroll
-        for (int r = 0; r < FPW; ++r) { const float dz = zD[r] - ztD[r]; fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz; }
-    }
-
-    // ---- kinematics constants of my quad's two items
+    // kinematics constants of my quad's two items
     const Pair* pp = a.w4pairs + b;
     PairC pc;
 #pragma unroll
@@ -557,22 +574,66 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     pc.subA = pp->ch_sub[0]; pc.subB = pp->ch_sub[1];
     pc.itemA = pp->item[0]; pc.itemB = pp->item[1];
     pc.kindB = pp->kind[1];
-    pc.qsA = FB_QS + 4 * pc.itemA;
-    pc.qsB = FB_QS + 4 * (pc.itemB >= 0 ? pc.itemB : QS_TRASH);
-    pc.bnA = FB_BN + 4 * pp->bone_slot[0];
-    pc.bnB = FB_BN + 4 * pp->bone_slot[1];
-    pc.wtA = FB_WT + 4 * (pp->kind[0] == KIND_JOINT ? pc.itemA : WT_ZERO);               // the root takes its torque from the root sum,
-    pc.wtB = FB_WT + 4 * (pc.kindB == KIND_JOINT && pc.itemB >= 0 ? pc.itemB : WT_ZERO); // virtual copies only carry a bone
-    pc.tab = pp->kind[0] == KIND_ROOT ? FB_RT : FB_GP;
+    const int kindA = pp->kind[0], slotA = pp->bone_slot[0], slotB = pp->bone_slot[1];
+    const ItemConst* ic = a.items + min(b, MAX_ROOT_CH - 1); // constant root-frame bones of the root's children (quads 0..2 store them)
+    const int init_id = ic->init_id;
+    const f4 init_off = {ic->init_off[0], ic->init_off[1], ic->init_off[2], 0.f};
+    const f2 adam_row = tid < a.n_iter ? f2{a.tab.step[tid], a.tab.bc2s[tid]} : f2{0.f, 0.f}; // (n_iter <= 256 = one row per thread)
+    __builtin_amdgcn_sched_barrier(0);
 
-    SETUP_STAMP(1);
-    // ---- trackers of my frame
+    // the streamed weight image (bL2), on its way into LDS (the only data the waves of a workgroup share), and the first half
+    // of the resident weight images: 66 loads per lane from the (L2-resident) global image.  (MFMA B operands,
+    // loop-invariant: L0, L1, L2A, L2B, bL1 = 61 groups = 244 accumulator registers; bL0's 5 groups in VECTOR registers --
+    // measured +2 % over streaming them; the accumulator half is full.)  Issuing them BLOCKS the wave for as long as the
+    // stream takes to drain into the memory pipeline -- which is time the first-level loads need anyway.
+    constexpr int N_ST = (NG_B2 * 64 + NW * 64 - 1) / (NW * 64);
+    f4 st[N_ST];
+#pragma unroll
+    for (int k = 0; k < N_ST; ++k)
+        if (tid + k * NW * 64 < NG_B2 * 64) st[k] = ((const f4*)a.w4img)[GR_B2 * 64 + tid + k * NW * 64];
+    f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15], wz[5];
+    const f4* wimg = (const f4*)a.w4img + lane;
+    load_w<6>(wL0, wimg + (S_L0 / 4) * 64);
+    load_w<10>(wL1, wimg + (S_L1 / 4) * 64);
+    load_w<15>(wL2A, wimg + (S_L2A / 4) * 64);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // second level, in the middle of the stream: the trackers of my frame (lane 4u+i: rank u of frame i)
     unsigned tmask = 0;
-    if (optimise)
-        for (int j = 0; j < NJ; ++j) tmask |= (a.tracked[(size_t)gfi * NJ + j] != 0 ? 1u : 0u) << j;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tmask |= (((tflag[j >> 2] >> (8 * (j & 3))) & 0xffu) ? 1u : 0u) << j;
+    if (!optimise) tmask = 0;
     const int E = min(__popc(tmask), W4_R);
     const int Emax = max(max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 1)),
                          max(__builtin_amdgcn_readlane(E, 2), __builtin_amdgcn_readlane(E, 3)));
+    const TRaw raw = tracker_fetch(a, optimise, gfi, tmask, E, b);
+    SETUP_STAMP(0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    load_w<15>(wL2B, wimg + (S_L2B / 4) * 64);
+    load_w<15>(wB1, wimg + (S_B1 / 4) * 64);
+    load_w<5>(wz, wimg + (S_B0 / 4) * 64);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- under the stream: frame blocks, trackers, LDS image
+    // what has to read as zero in a frame block: the own-torque slots of untracked joints, the two tracker tables (stage G
+    // reads rows beyond a frame's tracker count) and the bones' zero slot
+    constexpr int NZ = 32 + 2 * W4_R + 1;
+    for (int k = lane; k < FPW * NZ; k += 64) {
+        const int fr = k / NZ, r = k % NZ;
+        *(f4*)(fb0 + fr * FB_STRIDE + (r < 32 ? FB_WT + 4 * r : r < 32 + 2 * W4_R ? FB_GP + 4 * (r - 32) : FB_BN + 4 * SLOT_ZERO)) = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    static_assert(MAX_ITERS <= NW * 64, "one row of the Adam table per thread");
+    if (tid < a.n_iter) *(f2*)(lds + L_TAB + 2 * tid) = adam_row;
+    wave_sync(); // (the zero fill above and the tracker records below touch the same frame blocks from different lanes)
+
+    pc.qsA = FB_QS + 4 * pc.itemA;
+    pc.qsB = FB_QS + 4 * (pc.itemB >= 0 ? pc.itemB : QS_TRASH);
+    pc.bnA = FB_BN + 4 * slotA;
+    pc.bnB = FB_BN + 4 * slotB;
+    pc.wtA = FB_WT + 4 * (kindA == KIND_JOINT ? pc.itemA : WT_ZERO);                      // the root takes its torque from the root sum,
+    pc.wtB = FB_WT + 4 * (pc.kindB == KIND_JOINT && pc.itemB >= 0 ? pc.itemB : WT_ZERO); // virtual copies only carry a bone
+    pc.tab = kindA == KIND_ROOT ? FB_RT : FB_GP;
     {
         unsigned m = tmask;
 #pragma unroll
@@ -584,16 +645,28 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     }
     TRec trk;
     {
-        const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
         const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
-        trk = make_tracker(a, fb, gfi, tmask, E, b, cur); // lane 4u+i: tracker of rank u of frame i
-        for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur);
+        trk = tracker_finish(a, fb, raw, E, cur);
+        for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur); // (uniform, rare)
     }
     if (b == 0) *(f4*)(fb + FB_QS + 4 * QS_IDENT) = f4{1.f, 0.f, 0.f, 0.f};
-    if (b < MAX_ROOT_CH) { // constant root-frame bones of the root's children
-        const ItemConst* ic = a.items + b;
-        *(f4*)(fb + FB_BN + 4 * ic->init_id) = f4{ic->init_off[0], ic->init_off[1], ic->init_off[2], 0.f};
+    if (b < MAX_ROOT_CH) *(f4*)(fb + FB_BN + 4 * init_id) = init_off;
+    SETUP_STAMP(1);
+
+    f4 zfinD = zD;               // early stop: latent after a frame's last step
+    float es_prev = 10000000.f;  // early stop, lanes 0..3 (quad 0 = the root's) = frames: previous total loss (drag_pose.py:297),
+    bool es_act = true;          //   still iterating,
+    int es_iters = 0;            //   iterations executed
+    if (EARLY && lane < LAT) {
+#pragma unroll
+        for (int r = 0; r < FPW; ++r) { const float dz = zD[r] - ztD[r]; fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz; }
     }
+
+#pragma unroll
+    for (int k = 0; k < N_ST; ++k)
+        if (tid + k * NW * 64 < NG_B2 * 64) ((f4*)(lds + L_IMG2))[tid + k * NW * 64] = st[k];
+    __syncthreads();
+    if (f0 >= nB) return; // (uniform per wave) no barrier below this line
 
     SETUP_STAMP(2);
     wave_sync();
@@ -604,10 +677,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.start();
 #ifdef DP_PROFILE
     prof.t[10] = prof.prev - t_entry; // kernel entry -> first iteration
-    prof.t[12] = t_setup[0] - t_entry;    // staging, zeroing, barrier
-    prof.t[13] = t_setup[1] - t_setup[0]; // latent, bias rows, quad constants
-    prof.t[14] = t_setup[2] - t_setup[1]; // trackers
-    prof.t[15] = prof.prev - t_setup[2];  // resident weights
+    prof.t[12] = t_setup[0] - t_entry;    // first level, half of the stream, second level issued
+    prof.t[13] = t_setup[1] - t_setup[0]; // other half issued, frame blocks, trackers
+    prof.t[14] = t_setup[2] - t_setup[1]; // LDS image, barrier
+    prof.t[15] = prof.prev - t_setup[2];  // resident weights arrived
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;
 #endif
     for (int iter = 0; iter < a.n_iter; ++iter) {
@@ -762,6 +835,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             }
         }
         STAMP(9);
+#ifdef DP_PROFILE
+        if (iter == 0) prof.t[18] = prof.prev - mt0;               // the first iteration (cold instruction cache)
+        if (iter == 1) prof.t[19] = prof.prev - mt0 - prof.t[18];  // the second
+#endif
         if (EARLY && ((unsigned)__ballot(es_act && b == 0) & 0xFu) == 0u) break; // every frame of the wave has stopped
     }
 #ifdef DP_PROFILE
@@ -778,11 +855,15 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         }
     }
     wave_sync();
-    if (fvalid) {
-        const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
-        const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
-        w4_outputs(a, pp, 0, fb, gfi, optimise, cur, tmask, EARLY);
-        w4_outputs(a, pp, 1, fb, gfi, optimise, cur, tmask, EARLY);
+    {
+        const f4 cve = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
+        OutC oA, oB;
+        out_consts(a, pp, pc.itemA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, pc.itemB, pc.kindB, oA, oB);
+        if (fvalid) {
+            const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
+            w4_outputs(a, oA, fb, gfi, optimise, cur, tmask, EARLY);
+            w4_outputs(a, oB, fb, gfi, optimise, cur, tmask, EARLY);
+        }
     }
     if (optimise && lane < LAT) {
 #pragma unroll

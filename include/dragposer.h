@@ -25,6 +25,12 @@
  * allocation, no host synchronisation and no host<->device copy of caller data (graph-capturable).
  * One context per device; a context is not thread-safe; distinct contexts are independent.
  * There is NO CPU fallback: without a usable gfx950 device dp_create fails with DP_ERR_DEVICE.
+ *
+ * Skeletons the kernels are laid out for (dp_create returns DP_ERR_UNSUPPORTED with a message otherwise): 22 joints with
+ * parents[j] < j; at most 3 children of the root; at most 3 child bones beyond the first on all non-root joints together
+ * (Xsens: the two shoulders and the neck branching off the upper spine use 2); kinematic chains of at most 7 bones from the
+ * root.  The skeleton of the reference's data (the Xsens hierarchy every .bvh under python/data has, train.py:75-97)
+ * satisfies all four.
  */
 #ifndef DRAGPOSER_H
 #define DRAGPOSER_H

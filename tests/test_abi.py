@@ -95,3 +95,23 @@ def test_item_table_and_skeleton_validation():
     bad.parents[5] = 7
     buf = np.zeros(32 * 32, np.float32)
     assert lib.dp_debug_items(C.byref(bad.struct), buf.ctypes.data_as(C.c_void_p)) == _lib.DP_ERR_INVALID
+
+
+def test_skeleton_limits_are_reported():
+    """The limits include/dragposer.h states: <= 3 root children, <= 3 extra child bones, chains of <= 7 bones."""
+    lib = _lib.load()
+    buf = np.zeros(32 * 32, np.float32)
+
+    def rc_of(parents):
+        hm = HostModel()
+        hm.parents[:] = parents
+        return lib.dp_debug_items(C.byref(hm.struct), buf.ctypes.data_as(C.c_void_p))
+
+    ok = HostModel().parents.copy()
+    assert rc_of(ok) == _lib.DP_OK
+    star = np.zeros(22, np.int32)  # every joint a child of the root
+    assert rc_of(star) == _lib.DP_ERR_UNSUPPORTED and "root" in _lib.last_error()
+    chain = np.maximum(np.arange(22, dtype=np.int32) - 1, 0)  # one 21-bone chain
+    assert rc_of(chain) == _lib.DP_ERR_UNSUPPORTED and "7 bones" in _lib.last_error()
+    fan = np.array([0, 0] + [1] * 20, np.int32)  # joint 1 with 20 children
+    assert rc_of(fan) == _lib.DP_ERR_UNSUPPORTED and "extra child" in _lib.last_error()

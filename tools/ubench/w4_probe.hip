@@ -87,6 +87,34 @@ template <int NACC, int LDSW> __global__ __launch_bounds__(256, 1) void k_mfma_r
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
+// ---------------------------------------------------------------- 2b. the bf16 sibling: v_mfma_f32_4x4x4_16b_bf16 (K = 4 per instruction)
+typedef short s4v __attribute__((ext_vector_type(4)));
+template <int NACC> __global__ __launch_bounds__(256, 1) void k_bf16_rate(float* out, int iters, unsigned long long* cyc)
+{
+    const int l = threadIdx.x & 63;
+    f4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    s4v x = {(short)(0x3f80 + l), 0x3f80, 0x4000, 0x4040};
+    s4v w[24];
+#pragma unroll
+    for (int g = 0; g < 24; ++g) w[g] = s4v{(short)(0x3c00 + g), (short)(0x3c10 + l), 0x3c20, 0x3c30};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        static_for<96>([&](auto ki) {
+            constexpr int k = decltype(ki)::value;
+            acc[k % NACC] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(x, w[k % 24], acc[k % NACC], 4, k & 15, 0);
+        });
+        x[0] += (short)(acc[0][0] * 1e-30f);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
 // ---------------------------------------------------------------- 3. VALU issue: scalar vs packed fp32
 template <int MODE, int ILP> __global__ void k_valu(float* out, int iters, unsigned long long* cyc)
 {
@@ -244,6 +272,12 @@ int main()
     RUN_MFMA(1, 0, 256, 256) RUN_MFMA(2, 0, 256, 256) RUN_MFMA(4, 0, 256, 256)
     RUN_MFMA(1, 1, 256, 256) RUN_MFMA(2, 1, 256, 256) RUN_MFMA(4, 1, 256, 256)
     RUN_MFMA(2, 1, 1, 64)
+#define RUN_BF16(NACC, BLOCKS, THREADS)                                                                                     \
+    hipLaunchKernelGGL((k_bf16_rate<NACC>), dim3(BLOCKS), dim3(THREADS), 0, 0, out, iters, cyc);                             \
+    hipDeviceSynchronize();                                                                                                 \
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);                                                                           \
+    printf("mfma 4x4x4 bf16 (K = 4): %d acc, %d blocks x %d waves: %.2f cycles per MFMA\n", NACC, BLOCKS, THREADS / 64, (double)h / (iters * 96.0));
+    RUN_BF16(1, 1, 64) RUN_BF16(2, 1, 64) RUN_BF16(2, 256, 256) RUN_BF16(4, 256, 256)
 
     const int vit = 2000;
     const char* names[5] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_mul_f32"};
