@@ -6,8 +6,9 @@
 //   * Decoder forward / backward: v_mfma_f32_4x4x1_16b_f32 with the A-block broadcast (dp_w4.h): a step is a rank-1
 //     update of a 64-channel x 4-frame tile; activations stay in registers between layers (a 4x4 register <-> lane
 //     transpose inside lane quads turns a product's result into the next product's operand).  The weights of L0, L1,
-//     L2, bL1 (accumulator half of the register file) and bL0 (vector half) stay resident for the whole launch; those
-//     of bL2 are streamed from LDS (shared by the waves of a workgroup), requested a phase ahead of their use.
+//     L2, bL1 (accumulator half of the register file), bL0 (vector half) and the first 3-5 groups of bL2 (what is left of
+//     both) stay resident for the whole launch; the rest of bL2 is streamed from LDS (shared by the waves of a workgroup),
+//     requested a phase ahead of its use.
 //   * Kinematics: three stages per iteration, two wave-level LDS exchanges between them, all inside the wave.
 //       J  lane 4b+i = the two items of quad b (dp_w4.h) of frame i, both in one packed (v_pk_*) instruction stream:
 //          de-normalise, normalise, root-frame bone of the item's child (quaternion sandwich, no matrix);
@@ -143,7 +144,7 @@ DEV f4 add_halves(f4 v)
     }
     return v;
 }
-template <int NG> DEV void load_w(f4 (&wv)[NG], const f4* w)
+template <int NG> DEV void load_w(f4* wv, const f4* w)
 {
     static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; wv[g] = w[g * 64]; });
 }
@@ -513,6 +514,16 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, boo
 // EARLY: the reference's per-frame while-condition (drag_pose.py:298-304, 351-355).  A stopped frame keeps its pre-step
 // latent, so the forward passes it still takes part in reproduce its last one; a wave leaves the loop once all four of its
 // frames have stopped.
+// Head of bL2 kept resident beside the other products' weights: every streamed group costs the wave ~12 issue cycles per
+// iteration for its ds_read_b128 (measured: 3 / 4 / 5 resident groups = -0.8 / -1.1 / -1.3 % kernel time).  B2_RES_A groups
+// fill what is left of the accumulator half (244 + 12 = 256), B2_RES_V go to vector registers: 2 is what the fixed-count
+// kernel holds without spilling, the early-stop kernel (more live state) none.
+#ifndef W4_B2_RES_A
+#define W4_B2_RES_A 3
+#endif
+#ifndef W4_B2_RES_V
+#define W4_B2_RES_V 2
+#endif
 template <int NW, bool EARLY>
 __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 {
@@ -613,6 +624,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     load_w<15>(wL2B, wimg + (S_L2B / 4) * 64);
     load_w<15>(wB1, wimg + (S_B1 / 4) * 64);
     load_w<5>(wz, wimg + (S_B0 / 4) * 64);
+    constexpr int B2_RES_A = W4_B2_RES_A, B2_RES_V = EARLY ? 0 : W4_B2_RES_V, B2_RES = B2_RES_A + B2_RES_V;
+    f4 wB2a[B2_RES_A > 0 ? B2_RES_A : 1], wB2v[B2_RES_V > 0 ? B2_RES_V : 1]; // the head of bL2 (above)
+    load_w<B2_RES_A>(wB2a, wimg + (S_B2 / 4) * 64);
+    load_w<B2_RES_V>(wB2v, wimg + (S_B2 / 4 + B2_RES_A) * 64);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- under the stream: frame blocks, trackers, LDS image
@@ -736,10 +751,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, EARLY || last); // (uniform, rare)
         // bL2's weights leave LDS in three chunks (a read costs the wave its issue time wherever it stands -- the four waves of
         // a workgroup want the same LDS cycles -- so the chunks only have to be requested a phase ahead of their use, and be
-        // small enough for the register file): 8 groups across stage G, 8 ahead of the chain, 10 behind its first chunk (each
+        // small enough for the register file): the rest of the first 8 groups across stage G, 8 ahead of the chain, 10 behind its first chunk (each
         // pinned: the scheduler would move the reads next to their use)
-        f4 wq[8], wr[8], ws[10];
-        load_w<8>(wq, w2);
+        constexpr int NQ = 8 - B2_RES;
+        f4 wq[NQ], wr[8], ws[10];
+        load_w<NQ>(wq, w2 + B2_RES * 64);
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
         STAMP(4);
@@ -775,7 +791,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         load_w<8>(wr, w2 + 8 * 64);
         __builtin_amdgcn_sched_barrier(0);
         chain_begin();
-        chain_v<8, 0, 2>(acc0, acc1, gyA, wq);
+        chain_a<B2_RES_A, 0, 2>(acc0, acc1, gyA, wB2a);
+        chain_v<B2_RES_V, B2_RES_A>(acc0, acc1, gyA, wB2v);
+        chain_v<NQ, B2_RES>(acc0, acc1, gyA, wq);
         load_w<10>(ws, w2 + 16 * 64); // (into the registers the first chunk has just released)
         __builtin_amdgcn_sched_barrier(0);
         chain_v<8, 8>(acc0, acc1, gyA, wr);
