@@ -275,11 +275,13 @@ extern "C" int dp_debug_pack_w4(const dp_folded* f, const dp_model* m, float* im
         const int c0ch = dpw4::h0_channel(l); // the first hidden layer's channel in row l (dp_w4.h), or -1
         for (int k = 0; k < 24; ++k) put(dpw4::S_L0 + k, l, c0ch >= 0 ? f->A0[c0ch * 24 + k] : 0.f);
         for (int k = 0; k < 40; ++k) put(dpw4::S_L1 + k, l, l < 60 ? f->A1[l * 40 + k] : 0.f); // (K-step k = channel k: quads 0..4, 8..12)
-        const int ia = dpw4::item_of(0, l >> 2), ib = dpw4::item_of(1, l >> 2), c = l & 3;
-        const int ra = w4_src_row(pl, ia, c), rb = ib >= 0 ? w4_src_row(pl, ib, c) : -1;
+        // layer 2: row l of block blk = channel l2_channel(blk, l & 3) of the side-l2_side(l & 3) item of quad l >> 2 (dp_w4.h)
+        const int it2 = dpw4::item_of(dpw4::l2_side(l & 3), l >> 2);
+        const int ch2[2] = {dpw4::l2_channel(0, l & 3), dpw4::l2_channel(1, l & 3)};
+        const int r2[2] = {w4_src_row(pl, it2, ch2[0]), w4_src_row(pl, it2, ch2[1])};
         for (int k = 0; k < 60; ++k) {
-            put(dpw4::S_L2A + k, l, ra >= 0 ? (float)(sd_of(ia, c) * (double)f->A2[ra * 60 + k]) : 0.f);
-            put(dpw4::S_L2B + k, l, rb >= 0 ? (float)(sd_of(ib, c) * (double)f->A2[rb * 60 + k]) : 0.f);
+            put(dpw4::S_L2A + k, l, r2[0] >= 0 ? (float)(sd_of(it2, ch2[0]) * (double)f->A2[r2[0] * 60 + k]) : 0.f);
+            put(dpw4::S_L2B + k, l, r2[1] >= 0 ? (float)(sd_of(it2, ch2[1]) * (double)f->A2[r2[1] * 60 + k]) : 0.f);
         }
         for (int k = 0; k < 104; ++k) { // column k = channel k & 3 of an item of dL/dr (side A quads 0..15, then side B quads 1..10)
             const int item = k < 64 ? dpw4::item_of(0, k >> 2) : dpw4::item_of(1, dpw4::B2_ABID0_B + ((k - 64) >> 2));
@@ -291,8 +293,8 @@ extern "C" int dp_debug_pack_w4(const dp_folded* f, const dp_model* m, float* im
             put(dpw4::S_B0 + k, l, (l & 31) < 24 ? f->A0[((l < 32 ? 0 : 20) + k) * 24 + (l & 31)] : 0.f);
         bias[l] = c0ch >= 0 ? f->c0[c0ch] : 0.f;
         bias[64 + l] = l < 60 ? f->b1[l] : 0.f;
-        bias[128 + l] = (float)(sd_of(ia, c) * (ra >= 0 ? (double)f->b2[ra] : 0.0) + mu_of(ia, c));
-        bias[192 + l] = ib >= 0 ? (float)(sd_of(ib, c) * (rb >= 0 ? (double)f->b2[rb] : 0.0) + mu_of(ib, c)) : (c == 0 ? 1.f : 0.f);
+        for (int blk = 0; blk < 2; ++blk) // (idle items: sigma 0, mu (1, 0, 0, 0) -- they decode to the unit quaternion)
+            bias[128 + 64 * blk + l] = (float)(sd_of(it2, ch2[blk]) * (r2[blk] >= 0 ? (double)f->b2[r2[blk]] : 0.0) + mu_of(it2, ch2[blk]));
     }
     return DP_OK;
 }

@@ -25,8 +25,8 @@ constexpr int FPW = 4; // frames per wave
 // steps (K = 1 each) of the weight image, in program order; every product's count is a multiple of 4
 constexpr int S_L0 = 0;            // 24: rows = 40 channels of a0
 constexpr int S_L1 = S_L0 + 24;    // 40: rows = 60 channels of a1
-constexpr int S_L2A = S_L1 + 40;   // 60: rows = side-A items of y (4 channels each)
-constexpr int S_L2B = S_L2A + 60;  // 60: rows = side-B items of y
+constexpr int S_L2A = S_L1 + 40;   // 60: rows = channels 0, 1 of both items of every quad (l2_side / l2_channel below)
+constexpr int S_L2B = S_L2A + 60;  // 60: rows = channels 2, 3 of both items of every quad
 constexpr int S_B2 = S_L2B + 60;   // 104: K = 4 channels of the 16 side-A items, then of side-B quads 1..10; rows = 60 channels of d1
 constexpr int S_B1 = S_B2 + 104;   // 60: rows = 40 channels of d0
 constexpr int S_B0 = S_B1 + 60;    // 20: rows = 24 channels of dL/dz, K split over the two lane halves (below)
@@ -34,7 +34,7 @@ constexpr int N_STEPS = S_B0 + 20; // 368
 constexpr int N_GROUPS = N_STEPS / 4;
 // device image: [group][lane][4 steps] floats  (a lane's four steps are one ds_read_b128)
 constexpr int IMG_FLOATS = N_GROUPS * 64 * 4;
-// bias image [4][64]: L0, L1, L2A, L2B rows (the accumulators start from it)
+// bias image [4][64]: L0, L1, L2A, L2B rows (the C operand of each chain's first step)
 constexpr int BIAS_FLOATS = 4 * 64;
 
 // The 40 channels of the first hidden layer sit in rows (= lanes of layout D, = quads of layout X) 0..19 and 32..51:
@@ -44,6 +44,12 @@ constexpr int BIAS_FLOATS = 4 * 64;
 // 0..31 accumulate K-steps 0..19 and lanes 32..63 K-steps 20..39 of the same rows; one half-wave swap adds them.
 DP_HD constexpr int h0_row(int c) { return c < 20 ? c : 12 + c; }
 DP_HD constexpr int h0_channel(int row) { return row < 20 ? row : (row >= 32 && row < 52 ? row - 12 : -1); }
+
+// Rows of layer 2's two 64-row blocks: row 4b + r of block `blk` is channel 2 blk + (r >> 1) of the side-(r & 1) item of quad
+// b.  The transposed result of a block then has the SAME channel of the quad's two items in each even/odd register pair,
+// which is what the packed kinematics arithmetic (both items of a quad per instruction) reads -- no moves in between.
+DP_HD constexpr int l2_side(int r) { return r & 1; }
+DP_HD constexpr int l2_channel(int blk, int r) { return 2 * blk + (r >> 1); }
 
 // Kinematics items of a lane quad b: side A = item b (the 16 joints 0..15), side B = item 15 + b for b = 1..10 (joints
 // 16..21, the root displacement 22, virtual child-bone copies 23..25); quad 0's side B is idle, so that the root (side A

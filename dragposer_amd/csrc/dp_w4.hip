@@ -101,7 +101,18 @@ template <int ABID> DEV void group_v(f4& acc0, f4& acc1, const f4& x, const f4& 
                  "s_nop 0"                                                                                                \
                  : OUT0(acc0), "=&v"(acc1)                                                                                \
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
-template <int ABID> DEV void first_a_biased(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("a", "%0", "+v"); }
+// ... or a bias row: C = a register tuple that holds it for the whole launch, D = the accumulator (no copy per iteration)
+template <int ABID> DEV void first_a_biased(f4& acc0, f4& acc1, const f4& x, const f4& w, const f4& c)
+{
+    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %11 cbsz:4 abid:%10\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, 0 cbsz:4 abid:%10\n\t"
+                 "s_nop 0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"
+                 "s_nop 0"
+                 : "=&v"(acc0), "=&v"(acc1)
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "a"(w[0]), "a"(w[1]), "a"(w[2]), "a"(w[3]), "i"(ABID), "v"(c));
+}
 template <int ABID> DEV void first_a_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("a", "0", "=&v"); }
 template <int ABID> DEV void first_v_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("v", "0", "=&v"); }
 // a VALU result (transpose, kinematics) feeding the first MFMA of a chain / the chain's result feeding the VALU
@@ -109,12 +120,12 @@ DEV void chain_begin() { asm volatile("s_nop 1"); }
 DEV void chain_end(f4& acc0, f4& acc1) { asm volatile("s_nop 3" : "+v"(acc0), "+v"(acc1)); }
 
 // NG groups from resident weights (accumulator registers) / from weights in vector registers
-// START: 0 continues a chain; 1 starts one whose acc0 holds the bias row; 2 starts one from zero
-template <int NG, int ABID0, int START = 0> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv)
+// START: 0 continues a chain; 1 starts one from the bias row `bias`; 2 starts one from zero
+template <int NG, int ABID0, int START = 0> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv, const f4& bias = f4{0.f, 0.f, 0.f, 0.f})
 {
     static_for<NG>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
-        if constexpr (g == 0 && START == 1) first_a_biased<ABID0>(acc0, acc1, x, wv[0]);
+        if constexpr (g == 0 && START == 1) first_a_biased<ABID0>(acc0, acc1, x, wv[0], bias);
         else if constexpr (g == 0 && START == 2) first_a_zero<ABID0>(acc0, acc1, x, wv[0]);
         else group_a<ABID0 + g>(acc0, acc1, x, wv[g]);
     });
@@ -196,7 +207,7 @@ struct TRec { // a tracker as its T-stage lane sees it
     int qs, wt, rank;  // float index of the tracked joint's quaternion slot / own-torque slot; rank
     unsigned plo, phi; // bone slots on the path root -> joint (dp_layout.h: 7 x 5 bits)
     V3 tp;             // target position in the frame of cur_rot
-    Q4 qT;             // target rotation in the frame of cur_rot
+    f2 qT0, qT1;       // target rotation in the frame of cur_rot: (w, x), (y, z) -- register pairs for the packed products
     float cgp, clp, k8, clr8; // 2 w_pos / (3E), w_pos / (3E), -8 lam w_rot / (9E), 8 lam w_rot / (9E)
 };
 
@@ -272,12 +283,13 @@ DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur)
     t.plo = r.plo;
     t.phi = r.phi;
     t.tp = {0.f, 0.f, 0.f};
-    t.qT = {1.f, 0.f, 0.f, 0.f};
+    t.qT0 = f2{1.f, 0.f}; t.qT1 = f2{0.f, 0.f};
     t.cgp = t.clp = t.k8 = t.clr8 = 0.f;
     if (t.act) {
         const float invE = 1.f / (float)E;
         t.tp = rot_conj(cur, V3{r.p[0], r.p[1], r.p[2]});
-        t.qT = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, quat_from_rotmat(r.m));
+        const Q4 qT = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, quat_from_rotmat(r.m));
+        t.qT0 = f2{qT.w, qT.x}; t.qT1 = f2{qT.y, qT.z};
         t.clp = r.wp * invE * (1.f / 3.f);                       // loss_pos coefficient  w_pos / (3E)
         const float clr = a.lam_rot * r.wr * invE * (1.f / 9.f); // loss_rot coefficient  lam w_rot / (9E)
         t.cgp = 2.f * t.clp;
@@ -285,7 +297,7 @@ DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur)
         t.clr8 = 8.f * clr;
         float* ti = fb + FB_TI + r.rank * 4;
         *(f4*)(ti) = f4{t.tp.x, t.tp.y, t.tp.z, t.cgp};
-        *(f4*)(ti + 4 * W4_R) = f4{t.qT.w, t.qT.x, t.qT.y, t.qT.z};
+        *(f4*)(ti + 4 * W4_R) = f4{qT.w, qT.x, qT.y, qT.z};
         *(f4*)(ti + 8 * W4_R) = f4{t.k8, t.clp, t.clr8, __int_as_float(j)};
     }
     return t;
@@ -309,7 +321,7 @@ DEV TRec load_tracker(const KArgs& a, const float* fb, int E, int rank)
     t.phi = a.items[j].path_hi;
     t.tp = {i0.x, i0.y, i0.z};
     t.cgp = i0.w;
-    t.qT = {i1.x, i1.y, i1.z, i1.w};
+    t.qT0 = f2{i1.x, i1.y}; t.qT1 = f2{i1.z, i1.w};
     t.k8 = i2.x; t.clp = i2.y; t.clr8 = i2.z;
     return t;
 }
@@ -330,9 +342,9 @@ DEV void lds_store3(float* p, float a, float b, float c)
 
 // ---- stage J: both items of my quad, packed
 struct JOut { f2 q[4], u[3], inv; };
-DEV void j_stage(const PairC& c, float* fb, const f4 yA, const f4 yB, JOut& o)
-{
-    const f2 rq[4] = {f2{yA[0], yB[0]}, f2{yA[1], yB[1]}, f2{yA[2], yB[2]}, f2{yA[3], yB[3]}}; // (de-normalised by layer 2 itself)
+DEV void j_stage(const PairC& c, float* fb, const f4 y01, const f4 y23, JOut& o)
+{ // y01 / y23: the transposed blocks of layer 2 -- channels (0, 1) / (2, 3), each as a side A | side B register pair (dp_w4.h)
+    const f2 rq[4] = {f2{y01[0], y01[1]}, f2{y01[2], y01[3]}, f2{y23[0], y23[1]}, f2{y23[2], y23[3]}}; // (de-normalised by layer 2 itself)
     const f2 nn = rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3];
     const float invA = __builtin_amdgcn_rsqf(nn.x);
     const float invB = c.kindB == KIND_DISP ? 1.f : (c.kindB == KIND_IDLE ? 0.f : __builtin_amdgcn_rsqf(nn.y));
@@ -352,27 +364,64 @@ DEV void j_stage(const PairC& c, float* fb, const f4 yA, const f4 yB, JOut& o)
     lds_store3(fb + c.bnB, o.u[0].y, o.u[1].y, o.u[2].y);
 }
 
+// Quaternion products on register pairs (w, x), (y, z): eight packed instructions each, the operand swaps and signs of the
+// Hamilton product (and of the conjugate) expressed as op_sel / neg modifiers -- the compiler builds them with moves.
+//   (w, x) = aw (bw, bx) + ax (-bx, bw) + ay (-by, bz) + az (-bz, -by)
+//   (y, z) = aw (by, bz) + ax (-bz, by) + ay (bw, -bx) + az (bx, bw)
+// The ax term is the rounded product and the aw term the first fused one, then ay, az: the order the compiler gives
+// quat_mul (dp_device.h), so that the packed form is bit-identical to the scalar one.
+DEV void quat_mul_conj_a(f2 a0, f2 a1, f2 b0, f2 b1, f2& o0, f2& o1)
+{ // conj(a) (x) b
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %2, %5 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %5, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %5, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %3, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+        : "=&v"(o0), "=&v"(o1)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+DEV void quat_mul_conj_b(f2 a0, f2 a1, f2 b0, f2 b1, f2& o0, f2& o1)
+{ // a (x) conj(b)
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %2, %5 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %2, %5, %1 op_sel_hi:[0,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %3, %5, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(o0), "=&v"(o1)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+
 // ---- stage T: one tracker per lane
 DEV void t_stage(const TRec& t, float* fb, bool losses)
 {
     if (!t.act) return;
     const f4 q0v = *(const f4*)(fb + FB_QS), qtv = *(const f4*)(fb + t.qs), dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
-    V3 p = {dv.x, dv.y, dv.z}; // root-frame position: displacement + the bones on the path (short paths end in the zero slot)
+    f2 pxy = f2{dv.x, dv.y}; // root-frame position: displacement + the bones on the path (short paths end in the zero slot)
+    float pz = dv.z;
     {
         const unsigned plo = t.plo, phi = t.phi;
         f4 bn[MAX_PATH]; // all reads in flight together: one LDS latency, not seven
 #pragma unroll
         for (int k = 0; k < MAX_PATH; ++k) bn[k] = *(const f4*)(fb + FB_BN + 4 * ((k < 6) ? ((plo >> (5 * k)) & 31u) : (phi & 31u)));
 #pragma unroll
-        for (int k = 0; k < MAX_PATH; ++k) { p.x += bn[k].x; p.y += bn[k].y; p.z += bn[k].z; }
+        for (int k = 0; k < MAX_PATH; ++k) { pxy += f2{bn[k].x, bn[k].y}; pz += bn[k].z; }
     }
+    const V3 p = {pxy.x, pxy.y, pz};
     const Q4 q0 = {q0v.x, q0v.y, q0v.z, q0v.w};
     const V3 at = rot_conj(q0, t.tp); // target position in the root frame
     const V3 e = {p.x - at.x, p.y - at.y, p.z - at.z};
     const V3 gp = {t.cgp * e.x, t.cgp * e.y, t.cgp * e.z};
     // rotation error  s = conj(q0) (x) qT (x) conj(qt):  scalar part c = <q0 (x) qt, qT>,  |M - T|_F^2 = 8 |vec s|^2
-    const Q4 r = quat_mul(Q4{q0.w, -q0.x, -q0.y, -q0.z}, t.qT);
-    const Q4 s = quat_mul(r, Q4{qtv.x, -qtv.y, -qtv.z, -qtv.w});
+    f2 r0, r1, s0, s1;
+    quat_mul_conj_a(f2{q0v.x, q0v.y}, f2{q0v.z, q0v.w}, t.qT0, t.qT1, r0, r1);
+    quat_mul_conj_b(r0, r1, f2{qtv.x, qtv.y}, f2{qtv.z, qtv.w}, s0, s1);
+    const Q4 s = {s0.x, s0.y, s1.x, s1.y};
     const float k = t.k8 * s.w;
     const V3 own = {k * s.x, k * s.y, k * s.z}; // torque on the tracked joint (and on the root)
     const V3 ag = cross(at, gp);
@@ -686,6 +735,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SETUP_STAMP(2);
     wave_sync();
 
+    const f4 bias0T = splat(bias0), bias1T = splat(bias1), bias2aT = splat(bias2a), bias2bT = splat(bias2b); // C operands of the chains' first steps
     const f4 eT = {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f, i == 3 ? 1.f : 0.f}; // unit rows of the transposes
     JOut jo;
     Prof prof;
@@ -709,41 +759,40 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         // ================= L0: a0 = lrelu(A0 z + c0)
         f4 x = zD;
         QT(x);
-        f4 acc0 = splat(bias0), acc1;
+        f4 acc0, acc1;
         chain_begin();
-        chain_a<6, 0, 1>(acc0, acc1, x, wL0);
+        chain_a<6, 0, 1>(acc0, acc1, x, wL0, bias0T);
         chain_end(acc0, acc1);
         const f4 f0D = lrelu_factor(acc0 + acc1); // kept for the backward
         STAMP(0);
         // ================= L1: a1 = lrelu(A1 a0 + b1)
         x = (acc0 + acc1) * f0D;
         QT(x);
-        acc0 = splat(bias1);
         chain_begin();
-        chain_a<5, 0, 1>(acc0, acc1, x, wL1);   // the hidden layer's channels 0..19: quads 0..4,
+        chain_a<5, 0, 1>(acc0, acc1, x, wL1, bias1T); // the hidden layer's channels 0..19: quads 0..4,
         chain_a<5, 8>(acc0, acc1, x, wL1 + 5);  // 20..39: quads 8..12 (dp_w4.h)
         chain_end(acc0, acc1);
         const f4 f1D = lrelu_factor(acc0 + acc1);
         STAMP(1);
-        // ================= L2: y = A2 a1 + b2, two 64-row blocks (side A | side B items)
+        // ================= L2: y = A2 a1 + b2, two 64-row blocks (channels 0, 1 | 2, 3 of both items of every quad)
         x = (acc0 + acc1) * f1D;
         QT(x);
-        f4 yA, yB;
+        f4 y01, y23;
         {
-            f4 pa0 = splat(bias2a), pa1, pb0 = splat(bias2b), pb1;
+            f4 pa0, pa1, pb0, pb1;
             chain_begin();
-            chain_a<15, 0, 1>(pa0, pa1, x, wL2A);
-            chain_a<15, 0, 1>(pb0, pb1, x, wL2B);
+            chain_a<15, 0, 1>(pa0, pa1, x, wL2A, bias2aT);
+            chain_a<15, 0, 1>(pb0, pb1, x, wL2B, bias2bT);
             chain_end(pa0, pa1);
-            yA = pa0 + pa1;
-            yB = pb0 + pb1;
+            y01 = pa0 + pa1;
+            y23 = pb0 + pb1;
         }
-        QT(yA); // lane (b, i): the decoder quads of my two items of frame i
-        QT(yB);
+        QT(y01); // lane (b, i): the decoder channels of my two items of frame i, side A | side B in register pairs
+        QT(y23);
         STAMP(2);
 
         // ================= kinematics
-        j_stage(pc, fb, yA, yB, jo);
+        j_stage(pc, fb, y01, y23, jo);
         wave_sync();
         STAMP(3);
         if (!optimise) break; // forward-only launch (uniform)

@@ -38,8 +38,9 @@ def test_weight_image_is_the_folded_decoder(tables):
     hm = HostModel()
     x = rs.randn(60)
     y = f["A2"].astype(np.float64) @ x + f["b2"]
-    for s, s0 in ((0, W.S_L2A), (1, W.S_L2B)):
-        r = (W.product(img, s0, x) + bias[2 + s]).reshape(16, 4)
+    rq = W.layer2(img, bias, x)
+    for s in (0, 1):
+        r = rq[s]
         for b in range(16):
             item, kind = pairs["item"][b][s], pairs["kind"][b][s]
             if kind in (W.KIND_JOINT, W.KIND_ROOT, W.KIND_VIRT):

@@ -85,6 +85,12 @@ def lrelu(x):
     return np.maximum(x, 0.2 * x)
 
 
+def layer2(img, bias, a1):
+    """{side: [quad][channel]}: row 4b + r of block blk holds channel 2 blk + (r >> 1) of the side-(r & 1) item of quad b (dp_w4.h)"""
+    blocks = [(product(img, s0, a1) + bias[2 + k]).reshape(16, 4) for k, s0 in enumerate((S_L2A, S_L2B))]
+    return {s: np.stack([blocks[c >> 1][:, 2 * (c & 1) + s] for c in range(4)], axis=1) for s in (0, 1)}
+
+
 def one_iteration(tables, z, z_tgt, cur, tgt_pos, tgt_rot, w, tracked, lam_rot=1.0, lam_tmp=0.02):
     """one frame: (loss_pos, loss_rot, loss_tmp), dL/dz[24], and the per-item unit quaternions / bones it decoded"""
     img, bias, pairs, items = tables
@@ -92,7 +98,7 @@ def one_iteration(tables, z, z_tgt, cur, tgt_pos, tgt_rot, w, tracked, lam_rot=1
     # ---- decoder forward (accumulators start from the bias rows; L2 leaves DE-NORMALISED channels)
     a0 = lrelu(product(img, S_L0, z) + bias[0])[H0_ROW]
     a1 = lrelu(product(img, S_L1, a0) + bias[1])[:60]
-    rq = {0: (product(img, S_L2A, a1) + bias[2]).reshape(16, 4), 1: (product(img, S_L2B, a1) + bias[3]).reshape(16, 4)}
+    rq = layer2(img, bias, a1)
     # ---- stage J
     QS, BN = np.zeros((32, 4)), np.zeros((32, 3))
     QS[30] = [1, 0, 0, 0]
