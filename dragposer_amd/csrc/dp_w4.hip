@@ -160,6 +160,12 @@ template <int NG> DEV void load_w(f4* wv, const f4* w)
     static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; wv[g] = w[g * 64]; });
 }
 
+// an empty asm that "uses" NG weight groups (accumulator / vector registers): pins where the wait for their loads stands
+DEV void touch_a1(f4& w) { asm volatile("" : "+a"(w)); }
+DEV void touch_v1(f4& w) { asm volatile("" : "+v"(w)); }
+template <int NG> DEV void touch_a(f4* wv) { static_for<NG>([&](auto gi) { touch_a1(wv[decltype(gi)::value]); }); }
+template <int NG> DEV void touch_v(f4* wv) { static_for<NG>([&](auto gi) { touch_v1(wv[decltype(gi)::value]); }); }
+
 // D <-> X: transpose of (register index, lane-in-quad), on the matrix pipe: D_b[i][j] = sum_r x_r[i] * e_r[j] with
 // e_r[j] = (j == r) -- products with 1, sums with 0: exact.  Four dependent 2-pass MFMAs; the result may feed an MFMA
 // (4 wait states) or the VALU (4).  (The VALU form -- two exchange stages of v_cndmask_b32_dpp -- is in
@@ -735,6 +741,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SETUP_STAMP(2);
     wave_sync();
 
+    // every resident weight is "used" here, once: the waits for their loads then stand in front of the loop instead of in
+    // front of each weight's first use inside it (22 s_waitcnt vmcnt per iteration otherwise; no instruction is emitted)
+    touch_a<6>(wL0); touch_a<10>(wL1); touch_a<15>(wL2A); touch_a<15>(wL2B); touch_a<15>(wB1);
+    touch_a<B2_RES_A>(wB2a); touch_v<B2_RES_V>(wB2v); touch_v<5>(wz);
     const f4 bias0T = splat(bias0), bias1T = splat(bias1), bias2aT = splat(bias2a), bias2bT = splat(bias2b); // C operands of the chains' first steps
     const f4 eT = {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f, i == 3 ? 1.f : 0.f}; // unit rows of the transposes
     JOut jo;
