@@ -70,6 +70,24 @@ class DpSeqStep(C.Structure):
     ]
 
 
+class DpTemporalLayer(C.Structure):
+    _fields_ = [(n, _f) for n in (
+        "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
+        "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b", "norm3_w", "norm3_b")]
+
+
+class DpTemporalModel(C.Structure):
+    _fields_ = [
+        ("n_heights", C.c_int), ("dim_feedforward", C.c_int), ("n_encoder_layers", C.c_int), ("n_decoder_layers", C.c_int),
+        ("max_len", C.c_int), ("sample_step", C.c_int),
+        ("in_proj_encoder_w", _f), ("in_proj_encoder_b", _f), ("in_proj_decoder_w", _f), ("in_proj_decoder_b", _f),
+        ("out_proj_w", _f), ("out_proj_b", _f), ("pos_encoding", _f),
+        ("enc_norm_w", _f), ("enc_norm_b", _f), ("dec_norm_w", _f), ("dec_norm_b", _f),
+        ("means_latent", _f), ("stds_latent", _f),
+        ("enc", C.POINTER(DpTemporalLayer)), ("dec", C.POINTER(DpTemporalLayer)),
+    ]
+
+
 class DpResult(C.Structure):
     _fields_ = [
         ("z", C.c_void_p), ("z_pre", C.c_void_p), ("pose", C.c_void_p), ("disp", C.c_void_p),
@@ -82,6 +100,7 @@ class DpResult(C.Structure):
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
     "dp_forward", "dp_sequence_advance", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
+    "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict",
 )
 
 _lib = None
@@ -116,6 +135,11 @@ def load():
     lib.dp_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DpResult), C.c_void_p]
     lib.dp_sequence_advance.argtypes = [C.c_void_p, C.c_int, C.POINTER(DpResult), C.POINTER(DpSeqState), C.POINTER(DpSeqStep), C.c_void_p]
     lib.dp_kernel_geometry.argtypes = [C.c_void_p, _i, _i, _i]
+    lib.dp_temporal_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(DpTemporalModel), C.c_int]
+    lib.dp_temporal_destroy.argtypes = [C.c_void_p]
+    lib.dp_temporal_last_error.restype = C.c_char_p
+    lib.dp_temporal_last_error.argtypes = [C.c_void_p]
+    lib.dp_temporal_predict.argtypes = [C.c_void_p, C.c_int, C.POINTER(DpSeqState), C.c_int, C.c_void_p, C.c_void_p]
     # private test hooks (not part of include/dragposer.h)
     lib.dp_optimize_debug.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult),
                                       C.c_void_p, C.c_void_p]

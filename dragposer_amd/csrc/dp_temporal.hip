@@ -1,0 +1,367 @@
+// dp_temporal.hip -- the temporal predictor on the device (reference: Temporal, python/src/temporal_transformer.py:7-77,
+// positional_encoding.py:6-32; the temporal target block of DragPose.run, drag_pose.py:234-294).
+//
+// A torch.nn.Transformer (post-norm layers, ReLU, final encoder / decoder LayerNorm, no masks, dropout off) of width 48
+// over at most 32 tokens: far too small for one GPU to be busy with one sequence, so the unit of work is ONE WORKGROUP PER
+// SEQUENCE that runs the whole block -- token assembly from the history buffers, the encoder once, window / step + 1
+// autoregressive decoder calls (the reference passes no target mask, so every call recomputes all target positions),
+// de-normalisation and the step-hold "lerp" -- with every activation in LDS and the weights (5 MB fp32 at the reference's
+// size) streamed from L2.  All linear weights are stored TRANSPOSED ([in][out]) by dp_temporal_create, so that the lanes
+// of a wave, which own consecutive output columns, read consecutive words.
+// The feed-forward block (48 -> F -> 48, 94 % of the FLOPs) runs in chunks of 256 hidden units: a thread computes one
+// hidden unit for all tokens from a register-resident weight column, the chunk goes through LDS, and a thread (output
+// channel, token group) accumulates the second product over it.  fp32 throughout, sums in index order.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/dragposer.h"
+
+namespace {
+
+constexpr int D = DP_TEMPORAL_D_MODEL, NHD = DP_TEMPORAL_HEADS, HD = D / NHD, LAT = 24;
+constexpr int MAXT = DP_TEMPORAL_MAX_TOKENS, MAXL = DP_TEMPORAL_MAX_LAYERS;
+constexpr int NT = 256;       // threads per workgroup
+constexpr int FCH = 256;      // hidden units per feed-forward chunk (one per thread)
+constexpr int MAX_IN = 24 + 3 + DP_MAX_HEIGHT_JOINTS;
+constexpr int TPT = MAXT / 4; // tokens per thread in the second feed-forward product (4 token groups = 4 waves)
+
+struct TLayer { // offsets (in floats) into the device weight buffer
+    int sa_in_wT, sa_in_b, sa_out_wT, sa_out_b, ca_in_wT, ca_in_b, ca_out_wT, ca_out_b;
+    int lin1_wT, lin1_b, lin2_wT, lin2_b, n1w, n1b, n2w, n2b, n3w, n3b;
+};
+struct TArgs {
+    const float* w;
+    TLayer enc[MAXL], dec[MAXL];
+    int n_enc, n_dec, ff, n_in, nh, max_len, step;
+    int ipe_wT, ipe_b, ipd_wT, ipd_b, op_wT, op_b, pe, encn_w, encn_b, decn_w, decn_b, mean, stdv;
+    // per call
+    const float *latent_buf, *disp_buf, *heights_buf;
+    float* target;
+    int H, n_seq, window;
+};
+
+#define DEV __device__ __forceinline__
+
+// out[t][n] = b[n] + sum_k in[t][k] * wT[k][col0 + n]   (t < T, n < N; wT has ldw columns); optional add of pe[t][n]
+DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* wT, int ldw, int col0, const float* b, int N, int K,
+             const float* pe = nullptr)
+{
+    for (int idx = threadIdx.x; idx < T * N; idx += NT) {
+        const int t = idx / N, n = idx - t * N;
+        float acc = b[col0 + n];
+        const float* w = wT + col0 + n;
+        const float* x = in + t * ldi;
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[(size_t)k * ldw], acc);
+        if (pe) acc += pe[t * D + n];
+        out[t * ldo + n] = acc;
+    }
+    __syncthreads();
+}
+
+// x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm)
+DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
+{
+    for (int t = threadIdx.x; t < T; t += NT) {
+        float* xr = x + t * D;
+        float mean = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float v = xr[c] + (o ? o[t * D + c] : 0.f);
+            xr[c] = v;
+            mean += v;
+        }
+        mean *= 1.f / D;
+        float var = 0.f;
+        for (int c = 0; c < D; ++c) { const float d = xr[c] - mean; var = fmaf(d, d, var); }
+        const float r = 1.f / sqrtf(var * (1.f / D) + 1e-5f);
+        for (int c = 0; c < D; ++c) xr[c] = (xr[c] - mean) * r * g[c] + b[c];
+    }
+    __syncthreads();
+}
+
+// multi-head attention of Tq queries over Tk keys (no mask): ao[i][h*HD + c] = sum_j softmax_j(q_i . k_j / sqrt(HD)) v[j][h*HD + c]
+DEV void attention(float* ao, const float* q, const float* k, const float* v, float* sc, int Tq, int Tk)
+{
+    const float scale = 1.f / sqrtf((float)HD);
+    for (int idx = threadIdx.x; idx < NHD * Tq * Tk; idx += NT) {
+        const int h = idx / (Tq * Tk), r = idx - h * Tq * Tk, i = r / Tk, j = r - i * Tk;
+        float acc = 0.f;
+        for (int c = 0; c < HD; ++c) acc = fmaf(q[i * D + h * HD + c], k[j * D + h * HD + c], acc);
+        sc[(h * MAXT + i) * MAXT + j] = acc * scale;
+    }
+    __syncthreads();
+    for (int row = threadIdx.x; row < NHD * Tq; row += NT) {
+        const int h = row / Tq, i = row - h * Tq;
+        float* p = sc + (h * MAXT + i) * MAXT;
+        float m = p[0];
+        for (int j = 1; j < Tk; ++j) m = fmaxf(m, p[j]);
+        float s = 0.f;
+        for (int j = 0; j < Tk; ++j) { const float e = expf(p[j] - m); p[j] = e; s += e; }
+        const float r = 1.f / s;
+        for (int j = 0; j < Tk; ++j) p[j] *= r;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Tq * D; idx += NT) {
+        const int i = idx / D, col = idx - i * D, h = col / HD;
+        const float* p = sc + (h * MAXT + i) * MAXT;
+        float acc = 0.f;
+        for (int j = 0; j < Tk; ++j) acc = fmaf(p[j], v[j * D + col], acc);
+        ao[i * D + col] = acc;
+    }
+    __syncthreads();
+}
+
+// o = out_proj(attention(in_proj_q(xq), in_proj_k(xkv), in_proj_v(xkv)))
+DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const float* w, int in_wT, int in_b, int out_wT, int out_b,
+             float* q, float* k, float* v, float* ao, float* sc)
+{
+    lin(q, D, xq, D, Tq, w + in_wT, 3 * D, 0, w + in_b, D, D);
+    lin(k, D, xkv, D, Tk, w + in_wT, 3 * D, D, w + in_b, D, D);
+    lin(v, D, xkv, D, Tk, w + in_wT, 3 * D, 2 * D, w + in_b, D, D);
+    attention(ao, q, k, v, sc, Tq, Tk);
+    lin(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
+}
+
+// o[t] = linear2(relu(linear1(x[t])))
+DEV void ffn(float* o, const float* x, int T, const float* w, int F, int l1wT, int l1b, int l2wT, int l2b, float* hb)
+{
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6; // second product: output channel c (< 48), tokens g, g + 4, ...
+    float acc[TPT];
+#pragma unroll
+    for (int i = 0; i < TPT; ++i) acc[i] = 0.f;
+    for (int n0 = 0; n0 < F; n0 += FCH) {
+        { // hidden unit n0 + threadIdx.x for every token
+            const int n = n0 + threadIdx.x;
+            const bool live = n < F;
+            float wc[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) wc[k] = live ? w[l1wT + (size_t)k * F + n] : 0.f;
+            const float bias = live ? w[l1b + n] : 0.f;
+            for (int t = 0; t < T; ++t) {
+                float h = bias;
+#pragma unroll
+                for (int k = 0; k < D; ++k) h = fmaf(x[t * D + k], wc[k], h);
+                hb[t * FCH + threadIdx.x] = fmaxf(h, 0.f);
+            }
+        }
+        __syncthreads();
+        if (c < D) {
+            const int nn = min(FCH, F - n0);
+            for (int n = 0; n < nn; ++n) {
+                const float w2 = w[l2wT + (size_t)(n0 + n) * D + c];
+#pragma unroll
+                for (int i = 0; i < TPT; ++i) {
+                    const int t = g + 4 * i;
+                    if (t < T) acc[i] = fmaf(hb[t * FCH + n], w2, acc[i]); // (uniform per wave)
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (c < D) {
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+            const int t = g + 4 * i;
+            if (t < T) o[t * D + c] = acc[i] + w[l2b + c];
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
+{
+    __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D], q[MAXT * D], kb[MAXT * D], vb[MAXT * D], ao[MAXT * D];
+    __shared__ float sc[NHD * MAXT * MAXT], hb[MAXT * FCH], tok[(MAXT + 1) * LAT], enc_in[MAXT * MAX_IN], preds[(MAXT + 1) * LAT];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= a.n_seq) return;
+    const float* w = a.w;
+    const int H = a.H, step = a.step, n_past = (H + step - 1) / step, Te = n_past - 1, n_steps = a.window / step + 1;
+
+    // ---- tokens (drag_pose.py:249-266): latent normalised | displacement accumulated over `step` frames | heights
+    for (int idx = tid; idx < Te * a.n_in; idx += NT) {
+        const int t = idx / a.n_in, c = idx - t * a.n_in, fr = t * step;
+        float v;
+        if (c < LAT) v = (a.latent_buf[((size_t)s * H + fr) * LAT + c] - w[a.mean + c]) / w[a.stdv + c];
+        else if (c < LAT + 3) {
+            v = 0.f;
+            for (int j = 0; j < step && fr + j < H; ++j) v += a.disp_buf[((size_t)s * H + fr + j) * 3 + (c - LAT)];
+        } else v = a.heights_buf[((size_t)s * H + fr) * a.nh + (c - LAT - 3)];
+        enc_in[t * MAX_IN + c] = v;
+    }
+    if (tid < LAT) tok[tid] = (a.latent_buf[((size_t)s * H + Te * step) * LAT + tid] - w[a.mean + tid]) / w[a.stdv + tid];
+    __syncthreads();
+
+    // ---- encoder, once (the memory is the same for every autoregressive call)
+    lin(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
+    for (int l = 0; l < a.n_enc; ++l) {
+        const TLayer& L = a.enc[l];
+        mha(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
+        add_ln(x, o, Te, w + L.n1w, w + L.n1b);
+        ffn(o, x, Te, w, a.ff, L.lin1_wT, L.lin1_b, L.lin2_wT, L.lin2_b, hb);
+        add_ln(x, o, Te, w + L.n2w, w + L.n2b);
+    }
+    add_ln(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
+    for (int idx = tid; idx < Te * D; idx += NT) mem[idx] = x[idx];
+    __syncthreads();
+
+    // ---- autoregressive calls (drag_pose.py:274-279): call i sees i + 1 target tokens, keeps the last position's output
+    for (int it = 0; it < n_steps; ++it) {
+        const int T = it + 1;
+        lin(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
+        for (int l = 0; l < a.n_dec; ++l) {
+            const TLayer& L = a.dec[l];
+            mha(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
+            add_ln(x, o, T, w + L.n1w, w + L.n1b);
+            mha(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
+            add_ln(x, o, T, w + L.n2w, w + L.n2b);
+            ffn(o, x, T, w, a.ff, L.lin1_wT, L.lin1_b, L.lin2_wT, L.lin2_b, hb);
+            add_ln(x, o, T, w + L.n3w, w + L.n3b);
+        }
+        add_ln(x, nullptr, T, w + a.decn_w, w + a.decn_b);
+        lin(tok + T * LAT, LAT, x + (T - 1) * D, D, 1, w + a.op_wT, LAT, 0, w + a.op_b, LAT, D); // the next target token
+        if (tid < LAT) preds[it * LAT + tid] = tok[T * LAT + tid];
+        __syncthreads();
+    }
+
+    // ---- de-normalise, then the reference's "lerp" with weight 1 (drag_pose.py:283-291): frame k of the window holds the
+    //      NEXT sampled prediction, the last frame its own
+    const int W = a.window;
+    for (int idx = tid; idx < (W + 1) * LAT; idx += NT) {
+        const int k = idx / LAT, c = idx - k * LAT, m = k < W ? k / step + 1 : W / step;
+        a.target[((size_t)s * (W + 1) + k) * LAT + c] = preds[m * LAT + c] * w[a.stdv + c] + w[a.mean + c];
+    }
+}
+
+thread_local std::string g_terr;
+
+} // namespace
+
+struct dp_temporal {
+    int device = -1;
+    float* d_w = nullptr;
+    TArgs args{};
+    std::string err;
+};
+
+static int tfail(dp_temporal* t, int code, const std::string& msg)
+{
+    if (t) t->err = msg;
+    else g_terr = msg;
+    return code;
+}
+
+extern "C" const char* dp_temporal_last_error(const dp_temporal* t) { return t ? t->err.c_str() : g_terr.c_str(); }
+
+extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m, int device)
+{
+    if (!out) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: out is NULL");
+    *out = nullptr;
+    if (!m) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: model is NULL");
+    if (m->n_heights < 0 || m->n_heights > DP_MAX_HEIGHT_JOINTS || m->dim_feedforward < 1 || m->sample_step < 1 || m->max_len < 1 ||
+        m->n_encoder_layers < 1 || m->n_encoder_layers > MAXL || m->n_decoder_layers < 1 || m->n_decoder_layers > MAXL)
+        return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: architecture out of range (layers 1..8, heights <= 8)");
+    const int n_in = LAT + 3 + m->n_heights, F = m->dim_feedforward;
+    std::vector<float> buf;
+    bool null_seen = false;
+    auto put = [&](const float* p, size_t n) { // plain copy
+        const int off = (int)buf.size();
+        if (!p) { null_seen = true; buf.resize(buf.size() + n, 0.f); return off; }
+        buf.insert(buf.end(), p, p + n);
+        return off;
+    };
+    auto putT = [&](const float* p, int rows_out, int cols_in) { // Linear.weight [out][in] -> [in][out]
+        const int off = (int)buf.size();
+        buf.resize(buf.size() + (size_t)rows_out * cols_in, 0.f);
+        if (!p) { null_seen = true; return off; }
+        for (int r = 0; r < rows_out; ++r)
+            for (int c = 0; c < cols_in; ++c) buf[off + (size_t)c * rows_out + r] = p[(size_t)r * cols_in + c];
+        return off;
+    };
+    TArgs a{};
+    a.n_enc = m->n_encoder_layers; a.n_dec = m->n_decoder_layers; a.ff = F; a.n_in = n_in; a.nh = m->n_heights;
+    a.max_len = m->max_len; a.step = m->sample_step;
+    a.ipe_wT = putT(m->in_proj_encoder_w, D, n_in); a.ipe_b = put(m->in_proj_encoder_b, D);
+    a.ipd_wT = putT(m->in_proj_decoder_w, D, LAT); a.ipd_b = put(m->in_proj_decoder_b, D);
+    a.op_wT = putT(m->out_proj_w, LAT, D); a.op_b = put(m->out_proj_b, LAT);
+    a.pe = put(m->pos_encoding, (size_t)m->max_len * D);
+    a.encn_w = put(m->enc_norm_w, D); a.encn_b = put(m->enc_norm_b, D);
+    a.decn_w = put(m->dec_norm_w, D); a.decn_b = put(m->dec_norm_b, D);
+    a.mean = put(m->means_latent, LAT); a.stdv = put(m->stds_latent, LAT);
+    if (!m->enc || !m->dec) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: NULL layer array");
+    auto layer = [&](const dp_temporal_layer& L, bool dec) {
+        TLayer o{};
+        o.sa_in_wT = putT(L.sa_in_w, 3 * D, D); o.sa_in_b = put(L.sa_in_b, 3 * D);
+        o.sa_out_wT = putT(L.sa_out_w, D, D); o.sa_out_b = put(L.sa_out_b, D);
+        if (dec) {
+            o.ca_in_wT = putT(L.ca_in_w, 3 * D, D); o.ca_in_b = put(L.ca_in_b, 3 * D);
+            o.ca_out_wT = putT(L.ca_out_w, D, D); o.ca_out_b = put(L.ca_out_b, D);
+        }
+        o.lin1_wT = putT(L.lin1_w, F, D); o.lin1_b = put(L.lin1_b, F);
+        o.lin2_wT = putT(L.lin2_w, D, F); o.lin2_b = put(L.lin2_b, D);
+        o.n1w = put(L.norm1_w, D); o.n1b = put(L.norm1_b, D);
+        o.n2w = put(L.norm2_w, D); o.n2b = put(L.norm2_b, D);
+        if (dec) { o.n3w = put(L.norm3_w, D); o.n3b = put(L.norm3_b, D); }
+        return o;
+    };
+    for (int l = 0; l < a.n_enc; ++l) a.enc[l] = layer(m->enc[l], false);
+    for (int l = 0; l < a.n_dec; ++l) a.dec[l] = layer(m->dec[l], true);
+    if (null_seen) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: NULL tensor pointer in model");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return tfail(nullptr, DP_ERR_DEVICE, "dp_temporal_create: no HIP device (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: bad device index");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, DP_ERR_DEVICE, "dp_temporal_create: hipSetDevice failed");
+    dp_temporal* t = new dp_temporal;
+    t->device = device;
+    hipError_t e = hipMalloc((void**)&t->d_w, buf.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(t->d_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        if (t->d_w) (void)hipFree(t->d_w);
+        delete t;
+        return tfail(nullptr, DP_ERR_DEVICE, std::string("dp_temporal_create: ") + hipGetErrorString(e));
+    }
+    a.w = t->d_w;
+    t->args = a;
+    *out = t;
+    return DP_OK;
+}
+
+extern "C" int dp_temporal_destroy(dp_temporal* t)
+{
+    if (!t) return DP_ERR_INVALID;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(t->device);
+    if (t->d_w) (void)hipFree(t->d_w);
+    if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
+    delete t;
+    return DP_OK;
+}
+
+extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state* st, int window, float* target_buf, void* stream)
+{
+    if (!t) return DP_ERR_INVALID;
+    if (n_seq <= 0 || !st || !target_buf) return tfail(t, DP_ERR_INVALID, "dp_temporal_predict: bad arguments");
+    if (!st->latent_buf || !st->disp_buf || !st->heights_buf) return tfail(t, DP_ERR_INVALID, "dp_temporal_predict: NULL history buffer");
+    const TArgs& m = t->args;
+    if (st->n_heights != m.nh) return tfail(t, DP_ERR_INVALID, "dp_temporal_predict: state.n_heights differs from the model's");
+    if (window < 0 || window % m.step != 0) return tfail(t, DP_ERR_INVALID, "dp_temporal_predict: window must be a non-negative multiple of sample_step");
+    const int n_past = (st->history + m.step - 1) / m.step, n_steps = window / m.step + 1;
+    if (st->history < 2 * m.step || n_past - 1 > MAXT || n_steps > MAXT || n_past - 1 > m.max_len || n_steps > m.max_len)
+        return tfail(t, DP_ERR_UNSUPPORTED, "dp_temporal_predict: more than 32 encoder or decoder tokens (or more than max_len positions)");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != t->device && hipSetDevice(t->device) != hipSuccess) return tfail(t, DP_ERR_DEVICE, "cannot select the predictor's device");
+    TArgs a = m;
+    a.latent_buf = st->latent_buf; a.disp_buf = st->disp_buf; a.heights_buf = st->heights_buf;
+    a.H = st->history; a.n_seq = n_seq; a.window = window; a.target = target_buf;
+    hipLaunchKernelGGL(dp_temporal_kernel, dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return tfail(t, DP_ERR_LAUNCH, std::string("dp_temporal_predict: ") + hipGetErrorString(e));
+    return DP_OK;
+}

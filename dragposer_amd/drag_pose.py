@@ -40,13 +40,14 @@ def arrays_from_generator_model(generator_model, offsets):
 
 class DragPose:
     def __init__(self, generator_model, temporal_model, means_latent, stds_latent, device=None, device_gpu=None, n_sequences=1,
-                 offsets=None):
+                 offsets=None, native_temporal=False):
         """Argument order of the reference (drag_pose.py:13).  `generator_model` is one of
           * a `LatentOptimizer` (an existing kernel context; `device` arguments are then ignored),
           * None / a path to a model .npz / a dict of its arrays (dragposer_amd.model) -- a context is created on
             `device_gpu` (or `device` if that names a GPU, else cuda:0),
           * the reference's own Generator_Model object, with `offsets` [22,3] (see arrays_from_generator_model).
-        `n_sequences`: sequences advancing in lock-step (the reference: 1)."""
+        `n_sequences`: sequences advancing in lock-step (the reference: 1).  `native_temporal`: run the temporal target
+        block (drag_pose.py:248-292) in one HIP launch (dp_temporal_predict) instead of PyTorch ops around nn.Transformer."""
         if isinstance(generator_model, LatentOptimizer) or hasattr(generator_model, "host_model"):
             optimizer, arrays = generator_model, None
         else:
@@ -77,6 +78,11 @@ class DragPose:
         self.stds_latent = torch.as_tensor(stds_latent, dtype=torch.float32, device=dev)
         self.temporal_frames_index = list(PAST_FRAMES)
         self.target_latent_buffer = None
+        self._native_temporal = None
+        if native_temporal and self.temporal is not None:
+            from .temporal import NativeTemporal
+
+            self._native_temporal = NativeTemporal(self.temporal, self.means_latent, self.stds_latent, device=self.device)
         self.latent = None
         self.last = None
         self._idx_cache = {}
@@ -129,6 +135,10 @@ class DragPose:
         if self.target_latent_buffer is None or self.target_latent_buffer.shape[1] != window + 1:
             self.target_latent_buffer = torch.zeros(S, window + 1, LATENT, device=dev)
         if self.current_index != 0 or self.temporal is None:  # no predictor: the buffer stays zero, use lambda_temporal = 0
+            return
+        if self._native_temporal is not None:
+            self._native_temporal.predict(self.latent_buffer, self.displacement_buffer, self.heights_buffer, window,
+                                          out=self.target_latent_buffer)
             return
         idx = self.temporal_frames_index
         idx_t = self._index(idx)

@@ -173,6 +173,52 @@ typedef struct dp_seq_step {
 int dp_sequence_advance(dp_ctx* ctx, int n_sequences, const dp_result* res, const dp_seq_state* state, const dp_seq_step* step,
                         void* hip_stream);
 
+/* ---- temporal predictor (reference: Temporal, temporal_transformer.py:7-77, positional_encoding.py:6-32; its use in
+ * DragPose.run, drag_pose.py:234-294) -----------------------------------------------------------------------------
+ * The Transformer that predicts the latents of the next frames from the 60-frame history; its output is `z_tgt`, the
+ * anchor of the lambda_temporal term of dp_optimize.  torch.nn.Transformer semantics (post-norm layers, ReLU, final
+ * encoder / decoder LayerNorm, eps 1e-5, no masks, dropout off), fp32, one workgroup per sequence.
+ * All pointers of dp_temporal_model are HOST pointers to the tensors of the reference's state_dict, row-major as
+ * PyTorch stores them (Linear.weight = [out][in]). */
+#define DP_TEMPORAL_MAX_LAYERS 8
+#define DP_TEMPORAL_D_MODEL 48  /* features_transformer = 2 * latent_dim (train_temporal.py:26) */
+#define DP_TEMPORAL_HEADS 4     /* train_temporal.py:27 */
+#define DP_TEMPORAL_MAX_TOKENS 32 /* encoder tokens (ceil(H / sample_step) - 1) and decoder tokens (window / sample_step + 1) */
+typedef struct dp_temporal_layer {
+    const float *sa_in_w, *sa_in_b;   /* self_attn.in_proj_weight [144][48], in_proj_bias [144] */
+    const float *sa_out_w, *sa_out_b; /* self_attn.out_proj.weight [48][48], bias [48] */
+    const float *ca_in_w, *ca_in_b;   /* multihead_attn.* (decoder layers; NULL in encoder layers) */
+    const float *ca_out_w, *ca_out_b;
+    const float *lin1_w, *lin1_b;     /* linear1.weight [F][48], bias [F] */
+    const float *lin2_w, *lin2_b;     /* linear2.weight [48][F], bias [48] */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* [48] each */
+    const float *norm3_w, *norm3_b;   /* decoder layers; NULL in encoder layers */
+} dp_temporal_layer;
+typedef struct dp_temporal_model {
+    int n_heights;             /* heights per token (6: len(height_indices)) */
+    int dim_feedforward;       /* F (train_temporal.py:30: 2048) */
+    int n_encoder_layers, n_decoder_layers; /* <= DP_TEMPORAL_MAX_LAYERS */
+    int max_len;               /* rows of pos_encoding */
+    int sample_step;           /* train_temporal.py:15: 4 */
+    const float *in_proj_encoder_w, *in_proj_encoder_b; /* [48][24 + 3 + n_heights], [48] */
+    const float *in_proj_decoder_w, *in_proj_decoder_b; /* [48][24], [48] */
+    const float *out_proj_w, *out_proj_b;               /* [24][48], [24] */
+    const float* pos_encoding;                          /* [max_len][48] (positional_encoding.pos_encoding) */
+    const float *enc_norm_w, *enc_norm_b, *dec_norm_w, *dec_norm_b; /* temporal.encoder.norm / decoder.norm */
+    const float *means_latent, *stds_latent;            /* [24] (temporal.pt: means_latent / stds_latent) */
+    const dp_temporal_layer* enc; /* [n_encoder_layers] */
+    const dp_temporal_layer* dec; /* [n_decoder_layers] */
+} dp_temporal_model;
+typedef struct dp_temporal dp_temporal;
+int dp_temporal_create(dp_temporal** out, const dp_temporal_model* model, int device);
+int dp_temporal_destroy(dp_temporal* t);
+const char* dp_temporal_last_error(const dp_temporal* t); /* NULL: last failure of dp_temporal_create on this thread */
+/* The temporal target block of one frame step (drag_pose.py:248-292), for S sequences: tokens from the history buffers of
+ * `state` (latent normalised, displacement accumulated over sample_step frames, heights), window / sample_step + 1
+ * autoregressive calls of the Transformer, de-normalisation and the reference's step-hold "lerp".
+ * target_buf (DEVICE) [S][window + 1][24]: row current_index of it is the frame's z_tgt.  Asynchronous on the stream. */
+int dp_temporal_predict(dp_temporal* t, int n_sequences, const dp_seq_state* state, int window, float* target_buf, void* hip_stream);
+
 /* Device-buffer helpers for callers that have no HIP binding of their own (the native Unity drop-in,
  * include/dragposer_unity.h).  Thin wrappers over hipMalloc / hipFree / hipMemcpyAsync / hipStreamSynchronize on the
  * context's device; PyTorch callers never need them. */

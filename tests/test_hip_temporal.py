@@ -1,0 +1,109 @@
+"""GPU: the native temporal predictor (dp_temporal_*, csrc/dp_temporal.hip) -- the Transformer of
+temporal_transformer.py:7-77 and the temporal target block of drag_pose.py:248-292 in one HIP launch.
+Pinned twice: against the reference's own recorded `z_tgt` (tests/golden/seq*.npz: the real DragPose.run with the real
+Temporal class, whose state_dict the fixture carries), and against torch.nn.Transformer at the reference's full size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from test_temporal import _load_temporal
+
+pytestmark = pytest.mark.gpu
+STEP = 4
+
+
+def _torch_block(model, means, stds, lat, disp, hts, window):
+    """drag_pose.py:248-292 with torch ops on the CPU (float32), for S sequences"""
+    H = lat.shape[1]
+    idx = list(range(0, H, STEP))
+    with torch.no_grad():
+        enc_lat = (lat[:, idx[:-1]] - means) / stds
+        enc_disp = torch.stack([disp[:, j:j + STEP].sum(dim=1) for j in idx[:-1]], dim=1)
+        enc_in = torch.cat((enc_lat, enc_disp, hts[:, idx[:-1]]), dim=-1)
+        tgt = ((lat[:, idx[-1]] - means) / stds).unsqueeze(1)
+        buf = torch.zeros(lat.shape[0], window + 1, 24)
+        for i in range(0, window + 1, STEP):
+            pred = model(enc_in, tgt)
+            tgt = torch.cat((tgt, pred[:, -1:]), dim=1)
+            buf[:, i] = pred[:, -1]
+        buf = buf * stds + means
+        for i in range(0, window, STEP):
+            buf[:, i:i + STEP + 1] = buf[:, i + STEP].unsqueeze(1)
+    return buf
+
+
+@pytest.mark.parametrize("window", [0, 16, 60])
+def test_native_predictor_matches_nn_transformer_at_full_size(window):
+    from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+    torch.manual_seed(3)
+    model = TemporalPredictor().eval()  # 3 + 3 layers, d_model 48, 4 heads, feed-forward 2048 (train_temporal.py:17-37)
+    for p in model.parameters():  # default initialisation leaves biases / norms trivial: make every tensor matter
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(11)
+    S, H = 5, 60
+    means, stds = 0.2 * torch.randn(24, generator=g), 0.5 + torch.rand(24, generator=g)
+    lat, disp, hts = torch.randn(S, H, 24, generator=g), 0.02 * torch.randn(S, H, 3, generator=g), 1.0 + 0.3 * torch.randn(S, H, 6, generator=g)
+    want = _torch_block(model, means, stds, lat, disp, hts, window)
+    nat = NativeTemporal(model, means, stds, device="cuda:0")
+    got = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
+    assert got.shape == (S, window + 1, 24)
+    err = (got - want).abs().max().item()
+    print(f"window {window}: max |native - nn.Transformer| = {err:.2e} (targets of magnitude {want.abs().max().item():.2f})")
+    # fp32 against fp32 in a different summation order through 6 LayerNorm-ed layers and up to 16 autoregressive calls
+    assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("name", ["seq6", "seq3"])
+def test_native_predictor_reproduces_the_reference_targets(golden_dir, name):
+    """Closed loop over the reference-recorded sequences with the native predictor in the operator: the `z_tgt` it hands the
+    kernel, frame by frame, against the one the REFERENCE's Temporal produced (and the resulting state as in
+    test_hip_sequences)."""
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    g = R.load_golden(os.path.join(golden_dir, f"{name}.npz"))
+    mt, cfg = g["meta"], g["meta"]["cfg"]
+    K, T = mt["K"], mt["T"]
+    opt = LatentOptimizer(device="cuda:0")
+    dp = DragPose(opt, _load_temporal(g), g["means_latent"], g["stds_latent"], n_sequences=K, native_temporal=True)
+    assert dp._native_temporal is not None
+    dp.set_initial_state(g["z0"], np.zeros((K, 3), np.float32), g["init_rot"], g["init_heights"])
+    ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
+    zt_err, gpos_mm, iters_equal = [], [], []
+    for t in range(T):
+        idx = dp.current_index
+        pose, gpos = dp.run(g["tgt_pos"][t], g["tgt_rot"][t], g["mask_idx"], g["weights"], offsets=opt.host_model.arrays["offsets"],
+                            stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-2,
+                            lambda_rot=1, lambda_temporal=cfg["lambda_temporal"], temporal_future_window=cfg["temporal_future_window"],
+                            joint_adjustment_indices=ja, joint_adjustment_weight=cfg["joint_adjustment_weight"])
+        zt_err.append(np.abs(dp.target_latent_buffer[:, idx].cpu().numpy() - g["z_tgt"][t]).max())
+        gpos_mm.append(np.abs(gpos.cpu().numpy() - g["gpos_ret"][t]).max() * 1000.0)
+        iters_equal.append(dp.last["iters"].cpu().numpy() == g["iters"][t])
+    zt_err, gpos_mm, iters_equal = np.array(zt_err), np.array(gpos_mm), np.array(iters_equal)
+    print(f"{name}: max |z_tgt - reference| first 16 frames {zt_err[:16].max():.2e}, all {zt_err.max():.2e}; gpos {gpos_mm[:16].max():.4f} mm")
+    # the first 16 frames are the closed-loop window the torch-based operator is held to as well (test_hip_sequences.py)
+    assert zt_err[:16].max() <= 5e-5 and zt_err.max() <= 5e-4, (zt_err[:16].max(), zt_err.max())
+    assert gpos_mm[:16].max() <= 0.05 and iters_equal[:16].mean() >= 0.97
+
+
+def test_predictor_rejects_what_it_cannot_run():
+    from dragposer_amd import _lib
+    from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+    torch.manual_seed(0)
+    model = TemporalPredictor(n_encoder_layers=1, n_decoder_layers=1, dim_feedforward=32).eval()
+    nat = NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+    z = lambda *s: torch.zeros(*s, device="cuda:0")
+    with pytest.raises(_lib.DragPoserError):
+        nat.predict(z(1, 60, 24), z(1, 60, 3), z(1, 60, 6), 6)  # not a multiple of sample_step
+    with pytest.raises(_lib.DragPoserError):
+        nat.predict(z(1, 60, 24), z(1, 60, 3), z(1, 60, 5), 0)  # heights per token differ from the model's
+    with pytest.raises(_lib.DragPoserError):
+        nat.predict(z(1, 60, 24), z(1, 60, 3), z(1, 60, 6), 200)  # more target positions than pos_encoding has rows
+    out = nat.predict(z(2, 60, 24), z(2, 60, 3), z(2, 60, 6), 8)
+    assert torch.isfinite(out).all()

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic: time of one dp_temporal_predict launch (the whole temporal target block) at the reference's full size
+(3 + 3 layers, feed-forward 2048) against the number of sequences and the window, beside the PyTorch-ROCm operator path
+(nn.Transformer called window / 4 + 1 times).  Usage: tools/time_temporal.py"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+torch.manual_seed(0)
+dev = torch.device("cuda:0")
+model = TemporalPredictor().eval()
+nat = NativeTemporal(model, torch.zeros(24), torch.ones(24), device=dev)
+gm = model.to(dev)
+
+
+def torch_block(lat, disp, hts, window, step=4):
+    idx = list(range(0, lat.shape[1], step))
+    with torch.no_grad():
+        enc_in = torch.cat((lat[:, idx[:-1]], torch.stack([disp[:, j:j + step].sum(dim=1) for j in idx[:-1]], dim=1), hts[:, idx[:-1]]), dim=-1)
+        tgt = lat[:, idx[-1]].unsqueeze(1)
+        buf = torch.zeros(lat.shape[0], window + 1, 24, device=lat.device)
+        for i in range(0, window + 1, step):
+            pred = gm(enc_in, tgt)
+            tgt = torch.cat((tgt, pred[:, -1:]), dim=1)
+            buf[:, i] = pred[:, -1]
+    return buf
+
+
+for window in (0, 16, 60):
+    for S in (1, 64, 256, 1024, 4096):
+        lat, disp, hts = torch.randn(S, 60, 24, device=dev), torch.randn(S, 60, 3, device=dev), torch.randn(S, 60, 6, device=dev)
+        out = torch.empty(S, window + 1, 24, device=dev)
+        res = []
+        for fn in (lambda: nat.predict(lat, disp, hts, window, out=out), lambda: torch_block(lat, disp, hts, window)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            n = 5 if S >= 1024 else 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record(); e1.synchronize()
+            res.append(e0.elapsed_time(e1) / n)
+        print(f"window {window:2d} S={S:5d}: native {res[0]:9.3f} ms   torch ops {res[1]:9.3f} ms", flush=True)
