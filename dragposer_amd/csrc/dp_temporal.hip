@@ -8,9 +8,14 @@
 // de-normalisation and the step-hold "lerp" -- with every activation in LDS and the weights (5 MB fp32 at the reference's
 // size) streamed from L2.  All linear weights are stored TRANSPOSED ([in][out]) by dp_temporal_create, so that the lanes
 // of a wave, which own consecutive output columns, read consecutive words.
-// The feed-forward block (48 -> F -> 48, 94 % of the FLOPs) runs in chunks of 256 hidden units: a thread computes one
-// hidden unit for all tokens from a register-resident weight column, the chunk goes through LDS, and a thread (output
-// channel, token group) accumulates the second product over it.  fp32 throughout, sums in index order.
+// Every product runs on v_mfma_f32_16x16x4_f32 with the (at most 16, else tiled) tokens as one tile dimension:
+//   * linear layers: M = token, N = output channel, K = input channel; A from LDS, B one coalesced word per lane and K-step;
+//   * the feed-forward block (48 -> F -> 48, 94 % of the FLOPs and of the weight bytes), per tile of 16 hidden units:
+//     H^T = W1 X^T (M = hidden unit, N = token: 12 MFMAs), bias + ReLU in registers, then OUT += H W2^T with the
+//     accumulator of the first product AS the A operand of the second -- register r of lane (token, q) holds hidden unit
+//     4q + r of the tile, which is K-slot q of K-step r by definition of the packed W2 image (12 MFMAs, no LDS, no
+//     transposition).  The tiles are dealt to the 8 waves, weights arrive as 7 coalesced 16-byte loads per lane and tile
+//     (prefetched one tile ahead), the waves' partial outputs are summed through LDS.  fp32 throughout.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>
@@ -21,14 +26,14 @@ namespace {
 
 constexpr int D = DP_TEMPORAL_D_MODEL, NHD = DP_TEMPORAL_HEADS, HD = D / NHD, LAT = 24;
 constexpr int MAXT = DP_TEMPORAL_MAX_TOKENS, MAXL = DP_TEMPORAL_MAX_LAYERS;
-constexpr int NT = 256;       // threads per workgroup
-constexpr int FCH = 256;      // hidden units per feed-forward chunk (one per thread)
-constexpr int MAX_IN = 24 + 3 + DP_MAX_HEIGHT_JOINTS;
-constexpr int TPT = MAXT / 4; // tokens per thread in the second feed-forward product (4 token groups = 4 waves)
+constexpr int NT = 512, NWV = NT / 64;              // threads / waves per workgroup (two waves per SIMD)
+constexpr int MAX_IN = 36;                          // 24 + 3 + 8 heights, padded to a multiple of 4 (K-steps)
+constexpr int FFN_TILE_FLOATS = 7 * 64 * 4;         // packed feed-forward weights of one 16-unit tile: 7 float4 per lane
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct TLayer { // offsets (in floats) into the device weight buffer
     int sa_in_wT, sa_in_b, sa_out_wT, sa_out_b, ca_in_wT, ca_in_b, ca_out_wT, ca_out_b;
-    int lin1_wT, lin1_b, lin2_wT, lin2_b, n1w, n1b, n2w, n2b, n3w, n3b;
+    int ffn_pack, lin2_b, n1w, n1b, n2w, n2b, n3w, n3b; // ffn_pack: [ceil(F / 16)][7][64 lanes][4] (dp_temporal_create)
 };
 struct TArgs {
     const float* w;
@@ -43,18 +48,40 @@ struct TArgs {
 
 #define DEV __device__ __forceinline__
 
-// out[t][n] = b[n] + sum_k in[t][k] * wT[k][col0 + n]   (t < T, n < N; wT has ldw columns); optional add of pe[t][n]
+DEV f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// out[t][n] = b[col0 + n] + sum_k in[t][k] * wT[k][col0 + n] (+ pe[t][n])   (t < T, n < N, k < K <= 4 KS; wT has ldw columns)
+// One 16 x 16 output tile per wave and turn: A[token][k] from LDS, B[k][n] one word per lane and K-step -- all KS loads
+// of a tile in flight together.
+template <int KS>
 DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* wT, int ldw, int col0, const float* b, int N, int K,
              const float* pe = nullptr)
 {
-    for (int idx = threadIdx.x; idx < T * N; idx += NT) {
-        const int t = idx / N, n = idx - t * N;
-        float acc = b[col0 + n];
-        const float* w = wT + col0 + n;
-        const float* x = in + t * ldi;
-        for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[(size_t)k * ldw], acc);
-        if (pe) acc += pe[t * D + n];
-        out[t * ldo + n] = acc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    const int ntiles = (N + 15) >> 4, jobs = ntiles * ((T + 15) >> 4);
+    for (int job = wave; job < jobs; job += NWV) {
+        const int nt = job % ntiles, tt = job / ntiles, n = 16 * nt + l16, t = 16 * tt + l16;
+        float bw[KS], av[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 4 * ks + q;
+            bw[ks] = (k < K && n < N) ? wT[(size_t)k * ldw + col0 + n] : 0.f;
+            av[ks] = (k < K && t < T) ? in[t * ldi + k] : 0.f;
+        }
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            acc0 = mfma(av[ks], bw[ks], acc0);
+            if (ks + 1 < KS) acc1 = mfma(av[ks + 1], bw[ks + 1], acc1);
+        }
+        if (n < N) {
+            const float bias = b[col0 + n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int to = 16 * tt + 4 * q + r;
+                if (to < T) out[to * ldo + n] = acc0[r] + acc1[r] + bias + (pe ? pe[to * D + n] : 0.f);
+            }
+        }
     }
     __syncthreads();
 }
@@ -115,63 +142,78 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
 DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const float* w, int in_wT, int in_b, int out_wT, int out_b,
              float* q, float* k, float* v, float* ao, float* sc)
 {
-    lin(q, D, xq, D, Tq, w + in_wT, 3 * D, 0, w + in_b, D, D);
-    lin(k, D, xkv, D, Tk, w + in_wT, 3 * D, D, w + in_b, D, D);
-    lin(v, D, xkv, D, Tk, w + in_wT, 3 * D, 2 * D, w + in_b, D, D);
+    lin<D / 4>(q, D, xq, D, Tq, w + in_wT, 3 * D, 0, w + in_b, D, D);
+    lin<D / 4>(k, D, xkv, D, Tk, w + in_wT, 3 * D, D, w + in_b, D, D);
+    lin<D / 4>(v, D, xkv, D, Tk, w + in_wT, 3 * D, 2 * D, w + in_b, D, D);
     attention(ao, q, k, v, sc, Tq, Tk);
-    lin(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
+    lin<D / 4>(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
 }
 
-// o[t] = linear2(relu(linear1(x[t])))
-DEV void ffn(float* o, const float* x, int T, const float* w, int F, int l1wT, int l1b, int l2wT, int l2b, float* hb)
+// o[t] = linear2(relu(linear1(x[t]))) + bias2  (header comment; pack layout in dp_temporal_create)
+DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red)
 {
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6; // second product: output channel c (< 48), tokens g, g + 4, ...
-    float acc[TPT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    const int ntiles = (F + 15) >> 4;
+    const f4* img = (const f4*)(w + pack) + lane;
+    for (int tt = 0; tt < (T + 15) >> 4; ++tt) {
+        const int t = 16 * tt + l16;
+        float xb[D / 4]; // B operand of the first product: X^T[k][token]
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) acc[i] = 0.f;
-    for (int n0 = 0; n0 < F; n0 += FCH) {
-        { // hidden unit n0 + threadIdx.x for every token
-            const int n = n0 + threadIdx.x;
-            const bool live = n < F;
-            float wc[D];
+        for (int ks = 0; ks < D / 4; ++ks) xb[ks] = t < T ? x[t * D + 4 * ks + q] : 0.f;
+        f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f4 cur[7], nxt[7];
+        if (wave < ntiles) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) wc[k] = live ? w[l1wT + (size_t)k * F + n] : 0.f;
-            const float bias = live ? w[l1b + n] : 0.f;
-            for (int t = 0; t < T; ++t) {
-                float h = bias;
+            for (int v = 0; v < 7; ++v) cur[v] = img[((size_t)wave * 7 + v) * 64];
+        }
+        for (int nt = wave; nt < ntiles; nt += NWV) {
+            const bool more = nt + NWV < ntiles;
+            if (more) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) h = fmaf(x[t * D + k], wc[k], h);
-                hb[t * FCH + threadIdx.x] = fmaxf(h, 0.f);
+                for (int v = 0; v < 7; ++v) nxt[v] = img[((size_t)(nt + NWV) * 7 + v) * 64];
+            }
+            f4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+#pragma unroll
+            for (int ks = 0; ks < D / 4; ks += 2) {
+                h0 = mfma(cur[ks >> 2][ks & 3], xb[ks], h0);
+                h1 = mfma(cur[(ks + 1) >> 2][(ks + 1) & 3], xb[ks + 1], h1);
+            }
+            f4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = fmaxf(h0[r] + h1[r] + cur[6][r], 0.f); // hidden unit 16 nt + 4 q + r, token l16
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) { const int i = 3 * r + ct; acc[ct] = mfma(h[r], cur[3 + (i >> 2)][i & 3], acc[ct]); }
+            }
+            if (more) {
+#pragma unroll
+                for (int v = 0; v < 7; ++v) cur[v] = nxt[v];
             }
         }
-        __syncthreads();
-        if (c < D) {
-            const int nn = min(FCH, F - n0);
-            for (int n = 0; n < nn; ++n) {
-                const float w2 = w[l2wT + (size_t)(n0 + n) * D + c];
+        // the waves' partial outputs: lane (channel l16 of tile ct, token group q), register r = token 4 q + r
 #pragma unroll
-                for (int i = 0; i < TPT; ++i) {
-                    const int t = g + 4 * i;
-                    if (t < T) acc[i] = fmaf(hb[t * FCH + n], w2, acc[i]); // (uniform per wave)
-                }
+        for (int ct = 0; ct < 3; ++ct) *(f4*)(red + ((wave * 3 + ct) * 64 + lane) * 4) = acc[ct];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 16 * D; idx += NT) {
+            const int tl = idx / D, c = idx - tl * D, to = 16 * tt + tl;
+            if (to < T) {
+                const int slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
+                float sum = w[l2b + c];
+#pragma unroll
+                for (int wv = 0; wv < NWV; ++wv) sum += red[wv * 3 * 256 + slot];
+                o[to * D + c] = sum;
             }
         }
         __syncthreads();
     }
-    if (c < D) {
-#pragma unroll
-        for (int i = 0; i < TPT; ++i) {
-            const int t = g + 4 * i;
-            if (t < T) o[t * D + c] = acc[i] + w[l2b + c];
-        }
-    }
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
 {
     __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D], q[MAXT * D], kb[MAXT * D], vb[MAXT * D], ao[MAXT * D];
-    __shared__ float sc[NHD * MAXT * MAXT], hb[MAXT * FCH], tok[(MAXT + 1) * LAT], enc_in[MAXT * MAX_IN], preds[(MAXT + 1) * LAT];
+    __shared__ __attribute__((aligned(16))) float red[NWV * 3 * 64 * 4];
+    __shared__ float sc[NHD * MAXT * MAXT], tok[(MAXT + 1) * LAT], enc_in[MAXT * MAX_IN], preds[(MAXT + 1) * LAT];
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= a.n_seq) return;
     const float* w = a.w;
@@ -192,12 +234,12 @@ __global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
     __syncthreads();
 
     // ---- encoder, once (the memory is the same for every autoregressive call)
-    lin(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
+    lin<MAX_IN / 4>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
     for (int l = 0; l < a.n_enc; ++l) {
         const TLayer& L = a.enc[l];
         mha(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln(x, o, Te, w + L.n1w, w + L.n1b);
-        ffn(o, x, Te, w, a.ff, L.lin1_wT, L.lin1_b, L.lin2_wT, L.lin2_b, hb);
+        ffn(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
         add_ln(x, o, Te, w + L.n2w, w + L.n2b);
     }
     add_ln(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
@@ -207,18 +249,18 @@ __global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
     // ---- autoregressive calls (drag_pose.py:274-279): call i sees i + 1 target tokens, keeps the last position's output
     for (int it = 0; it < n_steps; ++it) {
         const int T = it + 1;
-        lin(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
+        lin<LAT / 4>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
         for (int l = 0; l < a.n_dec; ++l) {
             const TLayer& L = a.dec[l];
             mha(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
             add_ln(x, o, T, w + L.n1w, w + L.n1b);
             mha(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
             add_ln(x, o, T, w + L.n2w, w + L.n2b);
-            ffn(o, x, T, w, a.ff, L.lin1_wT, L.lin1_b, L.lin2_wT, L.lin2_b, hb);
+            ffn(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
             add_ln(x, o, T, w + L.n3w, w + L.n3b);
         }
         add_ln(x, nullptr, T, w + a.decn_w, w + a.decn_b);
-        lin(tok + T * LAT, LAT, x + (T - 1) * D, D, 1, w + a.op_wT, LAT, 0, w + a.op_b, LAT, D); // the next target token
+        lin<D / 4>(tok + T * LAT, LAT, x + (T - 1) * D, D, 1, w + a.op_wT, LAT, 0, w + a.op_b, LAT, D); // the next target token
         if (tid < LAT) preds[it * LAT + tid] = tok[T * LAT + tid];
         __syncthreads();
     }
@@ -277,6 +319,36 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
             for (int c = 0; c < cols_in; ++c) buf[off + (size_t)c * rows_out + r] = p[(size_t)r * cols_in + c];
         return off;
     };
+    // feed-forward image, per tile of 16 hidden units and lane (token / channel l16 = lane & 15, q = lane >> 4), 7 float4:
+    //   v = 0..2: W1[16 nt + l16][4 ks + q], ks = 4 v + e          (A operand of H^T = W1 X^T, K-step ks)
+    //   v = 3..5: W2[16 ct + l16][16 nt + 4 q + r], 3 r + ct = 4 (v - 3) + e   (B operand of OUT += H W2^T: K-step r, slot q)
+    //   v = 6:    bias1[16 nt + 4 q + e]
+    // hidden units beyond F are zero rows / columns (ReLU(0) = 0 contributes nothing)
+    auto pack_ffn = [&](const float* w1, const float* b1, const float* w2) {
+        while (buf.size() % 4) buf.push_back(0.f); // 16-byte alignment of the float4 image
+        const int off = (int)buf.size(), ntiles = (F + 15) / 16;
+        buf.resize(buf.size() + (size_t)ntiles * FFN_TILE_FLOATS, 0.f);
+        if (!w1 || !b1 || !w2) { null_seen = true; return off; }
+        for (int nt = 0; nt < ntiles; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int l16 = lane & 15, q = lane >> 4;
+                float* dst = buf.data() + off + (size_t)nt * FFN_TILE_FLOATS;
+                auto at = [&](int v, int e) -> float& { return dst[(v * 64 + lane) * 4 + e]; };
+                for (int ks = 0; ks < D / 4; ++ks) {
+                    const int n = 16 * nt + l16;
+                    at(ks >> 2, ks & 3) = n < F ? w1[(size_t)n * D + 4 * ks + q] : 0.f;
+                }
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * nt + 4 * q + r;
+                    for (int ct = 0; ct < 3; ++ct) {
+                        const int i = 3 * r + ct;
+                        at(3 + (i >> 2), i & 3) = n < F ? w2[(size_t)(16 * ct + l16) * F + n] : 0.f;
+                    }
+                    at(6, r) = n < F ? b1[n] : 0.f;
+                }
+            }
+        return off;
+    };
     TArgs a{};
     a.n_enc = m->n_encoder_layers; a.n_dec = m->n_decoder_layers; a.ff = F; a.n_in = n_in; a.nh = m->n_heights;
     a.max_len = m->max_len; a.step = m->sample_step;
@@ -296,8 +368,8 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
             o.ca_in_wT = putT(L.ca_in_w, 3 * D, D); o.ca_in_b = put(L.ca_in_b, 3 * D);
             o.ca_out_wT = putT(L.ca_out_w, D, D); o.ca_out_b = put(L.ca_out_b, D);
         }
-        o.lin1_wT = putT(L.lin1_w, F, D); o.lin1_b = put(L.lin1_b, F);
-        o.lin2_wT = putT(L.lin2_w, D, F); o.lin2_b = put(L.lin2_b, D);
+        o.ffn_pack = pack_ffn(L.lin1_w, L.lin1_b, L.lin2_w);
+        o.lin2_b = put(L.lin2_b, D);
         o.n1w = put(L.norm1_w, D); o.n1b = put(L.norm1_b, D);
         o.n2w = put(L.norm2_w, D); o.n2b = put(L.norm2_b, D);
         if (dec) { o.n3w = put(L.norm3_w, D); o.n3b = put(L.norm3_b, D); }
