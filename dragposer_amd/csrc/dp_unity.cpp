@@ -43,6 +43,7 @@ struct DragPoser {
     // model (load_models)
     std::map<std::string, Tensor> tensors;
     dp_ctx* ctx = nullptr;
+    dp_temporal* temporal = nullptr; // the temporal predictor, when <modelPath>/temporal.bin exists (tools/export_temporal_bin.py)
     std::vector<float> mean_q, std_q; // [88]
     // tracker set
     std::vector<int> mask_idx;
@@ -51,6 +52,8 @@ struct DragPoser {
     float stop_eps_pos = 1e-2f, stop_eps_rot = 1e-2f, lr = 1e-3f, lambda_rot = 1.f, lambda_tmp = 1.f;
     int max_iter = 100, window = 60;
     bool warned_temporal = false;
+    int current_index = 0;   // frame inside the temporal window (drag_pose.py:399-402)
+    int target_window = -1;  // window the device target buffer was sized for
     // state (drag_pose.py:47-64)
     bool initialised = false;
     float latent[LAT] = {0}, cur_pos[3] = {0, 0, 0};
@@ -59,6 +62,10 @@ struct DragPoser {
     // device staging: one input block, one output block
     void* d_in = nullptr;
     void* d_out = nullptr;
+    // device state of the sequence (drag_pose.py:47-64): global position / rotation and the three 60-frame history
+    // buffers, advanced by dp_sequence_advance; the temporal target buffer [window + 1][24]
+    void* d_state = nullptr;
+    void* d_target = nullptr;
 
     int fail(const std::string& m) { err = m; std::fprintf(stderr, "[DragPoserDLL] %s\n", m.c_str()); return -1; }
 };
@@ -68,6 +75,9 @@ namespace {
 // floats per frame in the staging blocks
 constexpr int IN_Z0 = 0, IN_ZT = 24, IN_ROT = 48, IN_TP = 52, IN_TR = IN_TP + NJ * 3, IN_W = IN_TR + NJ * 9, IN_TRK = IN_W + NJ * 2,
               IN_FLOATS = IN_TRK + 8; // tracked: 22 bytes in 8 floats
+constexpr int HIST = 60, NHGT = 6; // drag_pose.py:37-41, run_drag.py:153
+constexpr int ST_POS = 0, ST_ROT = 4, ST_LAT = 8, ST_DISP = ST_LAT + HIST * LAT, ST_HGT = ST_DISP + HIST * 3, ST_POSE = ST_HGT + HIST * NHGT,
+              ST_GPOS = ST_POSE + 88, ST_FLOATS = ST_GPOS + 4;
 constexpr int OUT_Z = 0, OUT_ZPRE = 24, OUT_POSE = 48, OUT_DISP = 136, OUT_WD = 140, OUT_WR = 144, OUT_POS = 148, OUT_LOSS = OUT_POS + NJ * 3,
               OUT_ITERS = OUT_LOSS + 4, OUT_FLOATS = OUT_ITERS + 4;
 
@@ -167,6 +177,80 @@ bool encode(const std::map<std::string, Tensor>& T, const std::vector<float>& po
     return true;
 }
 
+dp_seq_state seq_state(DragPoser* d)
+{
+    float* st = (float*)d->d_state;
+    dp_seq_state s;
+    std::memset(&s, 0, sizeof(s));
+    s.global_pos = st + ST_POS; s.global_rot = st + ST_ROT; s.latent_buf = st + ST_LAT; s.disp_buf = st + ST_DISP; s.heights_buf = st + ST_HGT;
+    s.history = HIST; s.n_heights = NHGT;
+    const int hj[NHGT] = {0, 4, 8, 13, 17, 21}; // run_drag.py:153
+    for (int i = 0; i < NHGT; ++i) s.height_joints[i] = hj[i];
+    return s;
+}
+
+// device state as DragPose.set_initial_pose leaves it (drag_pose.py:47-64): history filled with the initial latent,
+// zero displacements, the initial heights (the Unity path passes zeros, run_drag.py:93)
+bool reset_device_state(DragPoser* d)
+{
+    std::vector<float> st(ST_FLOATS, 0.f);
+    for (int a = 0; a < 3; ++a) st[ST_POS + a] = d->cur_pos[a];
+    st[ST_ROT] = d->cur_rot.w; st[ST_ROT + 1] = d->cur_rot.x; st[ST_ROT + 2] = d->cur_rot.y; st[ST_ROT + 3] = d->cur_rot.z;
+    for (int t = 0; t < HIST; ++t) std::memcpy(&st[ST_LAT + t * LAT], d->latent, sizeof(d->latent));
+    d->current_index = 0;
+    return dp_io_upload(d->ctx, d->d_state, st.data(), st.size() * sizeof(float), nullptr) == DP_OK && dp_stream_sync(d->ctx, nullptr) == DP_OK;
+}
+
+// <modelPath>/temporal.bin (DPM1, written by tools/export_temporal_bin.py from the reference's temporal.pt): the state_dict of
+// Temporal (temporal_transformer.py) + means_latent, stds_latent, sample_step
+bool load_temporal(DragPoser* d, const std::string& path, std::string& err)
+{
+    std::map<std::string, Tensor> T;
+    if (!load_bin(path, T, err)) return false;
+    auto get = [&](const std::string& k) -> const float* { auto it = T.find(k); if (it == T.end()) { err = path + ": no tensor " + k; return nullptr; } return it->second.data.data(); };
+    auto has = [&](const std::string& k) { return T.find(k) != T.end(); };
+    dp_temporal_model m;
+    std::memset(&m, 0, sizeof(m));
+    int n_enc = 0, n_dec = 0;
+    while (has("temporal.encoder.layers." + std::to_string(n_enc) + ".linear1.weight")) ++n_enc;
+    while (has("temporal.decoder.layers." + std::to_string(n_dec) + ".linear1.weight")) ++n_dec;
+    if (n_enc < 1 || n_dec < 1 || n_enc > DP_TEMPORAL_MAX_LAYERS || n_dec > DP_TEMPORAL_MAX_LAYERS || !has("in_proj_encoder.weight") ||
+        !has("positional_encoding.pos_encoding")) { err = path + ": not a Temporal state_dict"; return false; }
+    const Tensor& ipe = T["in_proj_encoder.weight"];
+    m.n_heights = (int)ipe.dims[1] - LAT - 3;
+    m.dim_feedforward = (int)T["temporal.encoder.layers.0.linear1.weight"].dims[0];
+    m.n_encoder_layers = n_enc; m.n_decoder_layers = n_dec;
+    m.max_len = (int)T["positional_encoding.pos_encoding"].dims[0];
+    m.sample_step = has("sample_step") ? (int)T["sample_step"].data[0] : 4; // train_temporal.py:15
+    std::vector<dp_temporal_layer> enc(n_enc), dec(n_dec);
+    bool ok = true;
+    auto fill = [&](dp_temporal_layer& L, const std::string& p, bool is_dec) {
+        std::memset(&L, 0, sizeof(L));
+        ok = ok && (L.sa_in_w = get(p + "self_attn.in_proj_weight")) && (L.sa_in_b = get(p + "self_attn.in_proj_bias")) &&
+             (L.sa_out_w = get(p + "self_attn.out_proj.weight")) && (L.sa_out_b = get(p + "self_attn.out_proj.bias")) &&
+             (L.lin1_w = get(p + "linear1.weight")) && (L.lin1_b = get(p + "linear1.bias")) && (L.lin2_w = get(p + "linear2.weight")) &&
+             (L.lin2_b = get(p + "linear2.bias")) && (L.norm1_w = get(p + "norm1.weight")) && (L.norm1_b = get(p + "norm1.bias")) &&
+             (L.norm2_w = get(p + "norm2.weight")) && (L.norm2_b = get(p + "norm2.bias"));
+        if (is_dec)
+            ok = ok && (L.ca_in_w = get(p + "multihead_attn.in_proj_weight")) && (L.ca_in_b = get(p + "multihead_attn.in_proj_bias")) &&
+                 (L.ca_out_w = get(p + "multihead_attn.out_proj.weight")) && (L.ca_out_b = get(p + "multihead_attn.out_proj.bias")) &&
+                 (L.norm3_w = get(p + "norm3.weight")) && (L.norm3_b = get(p + "norm3.bias"));
+    };
+    for (int l = 0; l < n_enc; ++l) fill(enc[l], "temporal.encoder.layers." + std::to_string(l) + ".", false);
+    for (int l = 0; l < n_dec; ++l) fill(dec[l], "temporal.decoder.layers." + std::to_string(l) + ".", true);
+    ok = ok && (m.in_proj_encoder_w = get("in_proj_encoder.weight")) && (m.in_proj_encoder_b = get("in_proj_encoder.bias")) &&
+         (m.in_proj_decoder_w = get("in_proj_decoder.weight")) && (m.in_proj_decoder_b = get("in_proj_decoder.bias")) &&
+         (m.out_proj_w = get("out_proj.weight")) && (m.out_proj_b = get("out_proj.bias")) && (m.pos_encoding = get("positional_encoding.pos_encoding")) &&
+         (m.enc_norm_w = get("temporal.encoder.norm.weight")) && (m.enc_norm_b = get("temporal.encoder.norm.bias")) &&
+         (m.dec_norm_w = get("temporal.decoder.norm.weight")) && (m.dec_norm_b = get("temporal.decoder.norm.bias")) &&
+         (m.means_latent = get("means_latent")) && (m.stds_latent = get("stds_latent"));
+    if (!ok) return false;
+    if (m.n_heights != NHGT) { err = path + ": the predictor takes " + std::to_string(m.n_heights) + " heights per token, the plugin feeds 6"; return false; }
+    m.enc = enc.data(); m.dec = dec.data();
+    if (dp_temporal_create(&d->temporal, &m, 0) != DP_OK) { err = std::string("dp_temporal_create: ") + dp_temporal_last_error(nullptr); return false; }
+    return true;
+}
+
 } // namespace
 
 extern "C" {
@@ -176,7 +260,13 @@ DragPoser* init_drag_poser(void) { return new DragPoser(); }
 const char* drag_poser_last_error(const DragPoser* d) { return d ? d->err.c_str() : "null handle"; }
 int drag_poser_last_iterations(const DragPoser* d) { return d ? d->last_iters : 0; }
 void drag_poser_get_latent(const DragPoser* d, float* z) { if (d && z) std::memcpy(z, d->latent, sizeof(d->latent)); }
-void drag_poser_set_latent(DragPoser* d, const float* z) { if (d && z) std::memcpy(d->latent, z, sizeof(d->latent)); }
+void drag_poser_set_latent(DragPoser* d, const float* z)
+{ // replaces the latent and re-initialises the history with it, as set_initial_pose does with the encoder's (drag_pose.py:50-55)
+    if (!d || !z) return;
+    std::memcpy(d->latent, z, sizeof(d->latent));
+    if (d->ctx && d->d_state && !reset_device_state(d)) d->fail(std::string("drag_poser_set_latent: ") + dp_last_error(d->ctx));
+}
+int drag_poser_has_temporal(const DragPoser* d) { return d && d->temporal ? 1 : 0; }
 
 void set_reference_skeleton(DragPoser* d, char* bvhPath)
 { // run_drag.py:30-38
@@ -216,15 +306,22 @@ void load_models(DragPoser* d, char* modelPath)
     m.parents = d->parents.data(); m.offsets = d->offsets.data();
     m.weight_dtype = DP_WEIGHTS_FP32;
     if (d->ctx) { // loaded before: release the previous context and its device buffers
-        if (d->d_in) dp_io_free(d->ctx, d->d_in);
-        if (d->d_out) dp_io_free(d->ctx, d->d_out);
-        d->d_in = d->d_out = nullptr;
+        for (void** p : {&d->d_in, &d->d_out, &d->d_state, &d->d_target}) { if (*p) dp_io_free(d->ctx, *p); *p = nullptr; }
+        if (d->temporal) dp_temporal_destroy(d->temporal);
+        d->temporal = nullptr;
+        d->target_window = -1;
         dp_destroy(d->ctx);
         d->ctx = nullptr;
     }
     if (dp_create(&d->ctx, &m, 0) != DP_OK) { d->fail(std::string("dp_create: ") + dp_last_error(nullptr)); return; }
-    if (dp_io_alloc(d->ctx, IN_FLOATS * sizeof(float), &d->d_in) != DP_OK || dp_io_alloc(d->ctx, OUT_FLOATS * sizeof(float), &d->d_out) != DP_OK)
+    if (dp_io_alloc(d->ctx, IN_FLOATS * sizeof(float), &d->d_in) != DP_OK || dp_io_alloc(d->ctx, OUT_FLOATS * sizeof(float), &d->d_out) != DP_OK ||
+        dp_io_alloc(d->ctx, ST_FLOATS * sizeof(float), &d->d_state) != DP_OK) {
         d->fail(std::string("device buffers: ") + dp_last_error(d->ctx));
+        return;
+    }
+    // the temporal predictor is optional: without temporal.bin the plugin runs with the pull term off (and says so)
+    const std::string tpath = std::string(modelPath) + "/temporal.bin";
+    if (std::ifstream(tpath, std::ios::binary).good() && !load_temporal(d, tpath, e)) d->fail(e);
 }
 
 void set_mask_and_weights(DragPoser* d, float* mask, dp_float2* weights)
@@ -249,6 +346,7 @@ void init_drag_model(DragPoser* d, dp_float3 pos, dp_quaternion rot)
     for (int i = 0; i < LAT; ++i) d->latent[i] = mu[i] + nd(gen) * std::exp(0.5f * logvar[i]); // autoencoder.py:19-27
     d->cur_pos[0] = pos.x; d->cur_pos[1] = pos.y; d->cur_pos[2] = pos.z;
     d->cur_rot = {rot.w, rot.x, rot.y, rot.z};
+    if (!reset_device_state(d)) { d->fail(std::string("init_drag_model: ") + dp_last_error(d->ctx)); return; }
     d->initialised = true;
 }
 
@@ -263,11 +361,11 @@ void set_lambdas(DragPoser* d, float lambdaRot, float lambdaTemporal, int tempor
     if (!d) return;
     d->lambda_rot = lambdaRot; d->lambda_tmp = lambdaTemporal; d->window = temporalFutureWindow;
     d->err.clear();
-    if (lambdaTemporal != 0.f) {
-        // The reference runs its temporal Transformer here (drag_pose.py:234-294).  This plugin has none: the call is
-        // accepted, the pull term stays off, and the difference is REPORTED through drag_poser_last_error (the reference ABI
-        // has no return codes) -- and once on stderr.
-        d->err = "set_lambdas: this build has no temporal predictor; lambdaTemporal = " + std::to_string(lambdaTemporal) +
+    if (lambdaTemporal != 0.f && !d->temporal) {
+        // The reference runs its temporal Transformer here (drag_pose.py:234-294).  Without <modelPath>/temporal.bin this
+        // plugin has none: the call is accepted, the pull term stays off, and the difference is REPORTED through
+        // drag_poser_last_error (the reference ABI has no return codes) -- and once on stderr.
+        d->err = "set_lambdas: no temporal predictor loaded (no temporal.bin in the model folder); lambdaTemporal = " + std::to_string(lambdaTemporal) +
                  " is treated as 0 (results differ from the reference's for a non-zero lambda)";
         if (!d->warned_temporal) {
             d->warned_temporal = true;
@@ -280,6 +378,9 @@ void set_global_pos(DragPoser* d, dp_float3 p)
 {
     if (!d) return;
     d->cur_pos[0] = p.x; d->cur_pos[1] = p.y; d->cur_pos[2] = p.z;
+    if (d->ctx && d->d_state && (dp_io_upload(d->ctx, (float*)d->d_state + ST_POS, d->cur_pos, sizeof(d->cur_pos), nullptr) != DP_OK ||
+                                 dp_stream_sync(d->ctx, nullptr) != DP_OK))
+        d->fail(std::string("set_global_pos: ") + dp_last_error(d->ctx));
 }
 
 void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quaternion* resultPose, dp_float3* resultGlobalPos)
@@ -294,7 +395,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     }
     float in[IN_FLOATS];
     std::memset(in, 0, sizeof(in));
-    std::memcpy(in + IN_Z0, d->latent, sizeof(d->latent)); // z_tgt stays 0: the pull term is off
+    std::memcpy(in + IN_Z0, d->latent, sizeof(d->latent)); // (the staged z_tgt stays 0: used when the pull term is off)
     in[IN_ROT] = d->cur_rot.w; in[IN_ROT + 1] = d->cur_rot.x; in[IN_ROT + 2] = d->cur_rot.y; in[IN_ROT + 3] = d->cur_rot.z;
     unsigned char* trk = (unsigned char*)(in + IN_TRK);
     for (int e = 0; e < nEE; ++e) {
@@ -310,9 +411,29 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     b.n_frames = 1;
     b.z0 = di + IN_Z0; b.z_tgt = di + IN_ZT; b.cur_rot = di + IN_ROT; b.tgt_pos = di + IN_TP; b.tgt_rot = di + IN_TR; b.w = di + IN_W;
     b.tracked = (const unsigned char*)(di + IN_TRK);
+    // temporal target block (drag_pose.py:234-294): a prediction every `window` frames, one row of it per frame
+    const bool pull = d->temporal && d->lambda_tmp != 0.f;
+    dp_seq_state st = seq_state(d);
+    if (pull) {
+        if (d->window < 0 || d->window % 4 != 0) { d->fail("drag_pose: temporalFutureWindow must be a non-negative multiple of 4 (sample_step)"); return; }
+        if (d->target_window != d->window) { // (re)sized and zeroed, as drag_pose.py:238-246 does
+            if (d->d_target) dp_io_free(d->ctx, d->d_target);
+            d->d_target = nullptr;
+            const std::vector<float> zeros((size_t)(d->window + 1) * LAT, 0.f);
+            if (dp_io_alloc(d->ctx, zeros.size() * sizeof(float), &d->d_target) != DP_OK ||
+                dp_io_upload(d->ctx, d->d_target, zeros.data(), zeros.size() * sizeof(float), nullptr) != DP_OK ||
+                dp_stream_sync(d->ctx, nullptr) != DP_OK) { d->fail(std::string("drag_pose: ") + dp_last_error(d->ctx)); return; }
+            d->target_window = d->window;
+        }
+        if (d->current_index == 0 && dp_temporal_predict(d->temporal, 1, &st, d->window, (float*)d->d_target, nullptr) != DP_OK) {
+            d->fail(std::string("drag_pose: ") + dp_temporal_last_error(d->temporal));
+            return;
+        }
+        b.z_tgt = (float*)d->d_target + (size_t)d->current_index * LAT;
+    }
     dp_params p;
     p.n_iter = d->max_iter; p.lr = d->lr; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f;
-    p.lambda_rot = d->lambda_rot; p.lambda_tmp = 0.f;
+    p.lambda_rot = d->lambda_rot; p.lambda_tmp = pull ? d->lambda_tmp : 0.f;
     p.early_stop = 1; p.stop_eps_pos = d->stop_eps_pos; p.stop_eps_rot = d->stop_eps_rot; p.min_loss_incr = 0.00001f; // run() default
     p.max_trackers = 0;
     dp_result r;
@@ -320,7 +441,12 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     r.z = dout + OUT_Z; r.z_pre = dout + OUT_ZPRE; r.pose = dout + OUT_POSE; r.disp = dout + OUT_DISP; r.world_disp = dout + OUT_WD;
     r.world_rot = dout + OUT_WR; r.pos = dout + OUT_POS; r.loss = dout + OUT_LOSS; r.iters = (int*)(dout + OUT_ITERS);
     float out[OUT_FLOATS];
+    dp_seq_step step; // the history buffers follow on the device (drag_pose.py:386-397); no joint adjustment on this path (run_drag.py:154)
+    std::memset(&step, 0, sizeof(step));
+    step.adjust_joint = -1; step.adjust_target_joint = -1;
+    step.pose_ret = (float*)d->d_state + ST_POSE; step.pos_ret = (float*)d->d_state + ST_GPOS;
     if (dp_io_upload(d->ctx, di, in, sizeof(in), nullptr) != DP_OK || dp_optimize(d->ctx, &b, &p, &r, nullptr) != DP_OK ||
+        dp_sequence_advance(d->ctx, 1, &r, &st, &step, nullptr) != DP_OK ||
         dp_io_download(d->ctx, out, dout, sizeof(out), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
         d->fail(std::string("drag_pose: ") + dp_last_error(d->ctx));
         return;
@@ -330,6 +456,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     for (int a = 0; a < 3; ++a) d->cur_pos[a] += out[OUT_WD + a];
     d->cur_rot = {out[OUT_WR], out[OUT_WR + 1], out[OUT_WR + 2], out[OUT_WR + 3]};
     std::memcpy(&d->last_iters, out + OUT_ITERS, sizeof(int));
+    d->current_index = d->window <= 0 ? 0 : (d->current_index + 1) % d->window; // drag_pose.py:399-402
     // result (run_drag.py:161-176): de-normalised root-space quaternions with the world root -> parent-local rotations
     Quat q[NJ];
     for (int j = 0; j < NJ; ++j) {
@@ -350,8 +477,8 @@ void destroy_drag_poser(DragPoser* d)
 {
     if (!d) return;
     if (d->ctx) {
-        if (d->d_in) dp_io_free(d->ctx, d->d_in);
-        if (d->d_out) dp_io_free(d->ctx, d->d_out);
+        for (void* p : {d->d_in, d->d_out, d->d_state, d->d_target}) if (p) dp_io_free(d->ctx, p);
+        if (d->temporal) dp_temporal_destroy(d->temporal);
         dp_destroy(d->ctx);
     }
     delete d;

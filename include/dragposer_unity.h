@@ -44,7 +44,9 @@ void destroy_drag_poser(DragPoser* dragPoser);                                  
 const char* drag_poser_last_error(const DragPoser* dragPoser); /* "" when the last call succeeded */
 int drag_poser_last_iterations(const DragPoser* dragPoser);    /* optimiser iterations of the last drag_pose */
 void drag_poser_get_latent(const DragPoser* dragPoser, float* latent24); /* the warm-start latent (tests, checkpointing) */
-void drag_poser_set_latent(DragPoser* dragPoser, const float* latent24);
+void drag_poser_set_latent(DragPoser* dragPoser, const float* latent24); /* also refills the latent history with it (drag_pose.py:50-55) */
+int drag_poser_has_temporal(const DragPoser* dragPoser); /* 1: <modelPath>/temporal.bin was loaded -- lambdaTemporal takes effect
+                                                            (the Transformer of temporal_transformer.py on the GPU, dp_temporal_*) */
 
 #ifdef __cplusplus
 }

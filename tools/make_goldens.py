@@ -380,6 +380,8 @@ def run_sequences(name, K, T, cfg, offsets_t, parents, seed):
         pos0, _, _, _ = forward_fk(drag, td, z0, cr, offsets_t)
         reset_state(drag, z0, cr)
         heights0 = pos0[height_idx, 1].clone()
+        if cfg.get("unity_initial_heights"):  # what the Unity path passes (run_drag.py:93: torch.zeros(6))
+            heights0 = torch.zeros(6)
         drag.heights_buffer[:] = heights0
         out["z0"][k], out["init_rot"][k], out["init_heights"][k] = z0.numpy(), cr.numpy(), heights0.numpy()
         gt_rot, gt_pos = cr.clone(), torch.zeros(3)
@@ -426,7 +428,7 @@ def run_sequences(name, K, T, cfg, offsets_t, parents, seed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3,enc")
+    ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3,sequ,enc")
     ap.add_argument("--frames", type=int, default=64)
     args = ap.parse_args()
     todo = args.only.split(",")
@@ -462,7 +464,10 @@ def main():
         path = os.path.join(gold, "enc.npz")
         np.savez_compressed(path, **encoder_golden(parents))
         print("wrote", path, os.path.getsize(path), "bytes", flush=True)
-    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78)):
+    # "sequ": the shape of the Unity path (run_drag.py:141-157): one sequence, no joint adjustment, zero initial heights,
+    # the temporal term on with a window that takes several autoregressive calls
+    cfgu = dict(cfg6, enable_joint_adjustment=False, lambda_temporal=0.02, temporal_future_window=8, unity_initial_heights=True)
+    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78), ("sequ", cfgu, 1, 24, 79)):
         if name in todo:
             out = run_sequences(name, K, T, cfg, offsets_t, parents, seed)
             path = os.path.join(gold, f"{name}.npz")
