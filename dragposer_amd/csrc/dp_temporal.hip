@@ -15,7 +15,7 @@
 //     accumulator of the first product AS the A operand of the second -- register r of lane (token, q) holds hidden unit
 //     4q + r of the tile, which is K-slot q of K-step r by definition of the packed W2 image (12 MFMAs, no LDS, no
 //     transposition).  The tiles are dealt to the 8 waves, weights arrive as 7 coalesced 16-byte loads per lane and tile
-//     (prefetched one tile ahead), the waves' partial outputs are summed through LDS.  fp32 throughout.
+//     (four waves per SIMD cover their latency), the waves' partial outputs are summed through LDS.  fp32 throughout.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>
@@ -37,7 +37,8 @@ struct TLayer { // offsets (in floats) into the device weight buffer
 };
 struct TArgs {
     const float* w;
-    TLayer enc[MAXL], dec[MAXL];
+    int enc_tab, dec_tab; // offsets of the TLayer tables inside the weight buffer (a kernel-argument array indexed by the
+                          // layer loop would be copied into registers: 288 SGPRs)
     int n_enc, n_dec, ff, n_in, nh, max_len, step;
     int ipe_wT, ipe_b, ipd_wT, ipd_b, op_wT, op_b, pe, encn_w, encn_b, decn_w, decn_b, mean, stdv;
     // per call
@@ -57,8 +58,12 @@ template <int KS>
 DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* wT, int ldw, int col0, const float* b, int N, int K,
              const float* pe = nullptr)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // opaque per call: the per-lane weight addresses are recomputed (a few VALU operations) instead
+                                   // of being hoisted out of the layer loops into registers the kernel does not have
+    const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
     const int ntiles = (N + 15) >> 4, jobs = ntiles * ((T + 15) >> 4);
+#pragma unroll 1
     for (int job = wave; job < jobs; job += NWV) {
         const int nt = job % ntiles, tt = job / ntiles, n = 16 * nt + l16, t = 16 * tt + l16;
         float bw[KS], av[KS];
@@ -86,22 +91,28 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
     __syncthreads();
 }
 
-// x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm)
+DEV float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm): one wave per token, one
+// lane per channel
 DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 {
-    for (int t = threadIdx.x; t < T; t += NT) {
-        float* xr = x + t * D;
-        float mean = 0.f;
-        for (int c = 0; c < D; ++c) {
-            const float v = xr[c] + (o ? o[t * D + c] : 0.f);
-            xr[c] = v;
-            mean += v;
-        }
-        mean *= 1.f / D;
-        float var = 0.f;
-        for (int c = 0; c < D; ++c) { const float d = xr[c] - mean; var = fmaf(d, d, var); }
-        const float r = 1.f / sqrtf(var * (1.f / D) + 1e-5f);
-        for (int c = 0; c < D; ++c) xr[c] = (xr[c] - mean) * r * g[c] + b[c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = lane < D;
+    const float gc = live ? g[lane] : 0.f, bc = live ? b[lane] : 0.f;
+#pragma unroll 1
+    for (int t = wave; t < T; t += NWV) {
+        float v = 0.f;
+        if (live) v = x[t * D + lane] + (o ? o[t * D + lane] : 0.f);
+        const float mean = wave_sum(v) * (1.f / D);
+        const float d = live ? v - mean : 0.f;
+        const float r = 1.f / sqrtf(wave_sum(d * d) * (1.f / D) + 1e-5f);
+        if (live) x[t * D + lane] = d * r * gc + bc;
     }
     __syncthreads();
 }
@@ -152,26 +163,25 @@ DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const 
 // o[t] = linear2(relu(linear1(x[t]))) + bias2  (header comment; pack layout in dp_temporal_create)
 DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (as in lin)
+    const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
     const int ntiles = (F + 15) >> 4;
     const f4* img = (const f4*)(w + pack) + lane;
+#pragma unroll 1
     for (int tt = 0; tt < (T + 15) >> 4; ++tt) {
         const int t = 16 * tt + l16;
         float xb[D / 4]; // B operand of the first product: X^T[k][token]
 #pragma unroll
         for (int ks = 0; ks < D / 4; ++ks) xb[ks] = t < T ? x[t * D + 4 * ks + q] : 0.f;
         f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        f4 cur[7], nxt[7];
-        if (wave < ntiles) {
-#pragma unroll
-            for (int v = 0; v < 7; ++v) cur[v] = img[((size_t)wave * 7 + v) * 64];
-        }
+        // (no software prefetch: with four waves per SIMD the other waves cover the load latency, and the registers of a
+        //  second tile image would not fit the 128 a wave has at that occupancy)
+#pragma unroll 1
         for (int nt = wave; nt < ntiles; nt += NWV) {
-            const bool more = nt + NWV < ntiles;
-            if (more) {
+            f4 cur[7];
 #pragma unroll
-                for (int v = 0; v < 7; ++v) nxt[v] = img[((size_t)(nt + NWV) * 7 + v) * 64];
-            }
+            for (int v = 0; v < 7; ++v) cur[v] = img[((size_t)nt * 7 + v) * 64];
             f4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
 #pragma unroll
             for (int ks = 0; ks < D / 4; ks += 2) {
@@ -185,10 +195,6 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) { const int i = 3 * r + ct; acc[ct] = mfma(h[r], cur[3 + (i >> 2)][i & 3], acc[ct]); }
-            }
-            if (more) {
-#pragma unroll
-                for (int v = 0; v < 7; ++v) cur[v] = nxt[v];
             }
         }
         // the waves' partial outputs: lane (channel l16 of tile ct, token group q), register r = token 4 q + r
@@ -209,10 +215,14 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
     }
 }
 
-__global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
+__global__ __launch_bounds__(NT, 4) void dp_temporal_kernel(const TArgs a) // (4 waves per SIMD = two workgroups per CU)
 {
-    __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D], q[MAXT * D], kb[MAXT * D], vb[MAXT * D], ao[MAXT * D];
-    __shared__ __attribute__((aligned(16))) float red[NWV * 3 * 64 * 4];
+    __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D];
+    // q, k, v and the attention output; dead while the feed-forward block runs, whose cross-wave reduction buffer is the
+    // same 24 KB (70 KB of LDS in all: two workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float qkva[4 * MAXT * D];
+    static_assert(4 * MAXT * D >= NWV * 3 * 64 * 4, "the reduction buffer fits the attention buffers");
+    float *q = qkva, *kb = qkva + MAXT * D, *vb = qkva + 2 * MAXT * D, *ao = qkva + 3 * MAXT * D, *red = qkva;
     __shared__ float sc[NHD * MAXT * MAXT], tok[(MAXT + 1) * LAT], enc_in[MAXT * MAX_IN], preds[(MAXT + 1) * LAT];
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= a.n_seq) return;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
     // ---- encoder, once (the memory is the same for every autoregressive call)
     lin<MAX_IN / 4>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
     for (int l = 0; l < a.n_enc; ++l) {
-        const TLayer& L = a.enc[l];
+        const TLayer L = ((const TLayer*)(w + a.enc_tab))[l];
         mha(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln(x, o, Te, w + L.n1w, w + L.n1b);
         ffn(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(NT) void dp_temporal_kernel(const TArgs a)
         const int T = it + 1;
         lin<LAT / 4>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
         for (int l = 0; l < a.n_dec; ++l) {
-            const TLayer& L = a.dec[l];
+            const TLayer L = ((const TLayer*)(w + a.dec_tab))[l];
             mha(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
             add_ln(x, o, T, w + L.n1w, w + L.n1b);
             mha(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
@@ -375,8 +385,14 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
         if (dec) { o.n3w = put(L.norm3_w, D); o.n3b = put(L.norm3_b, D); }
         return o;
     };
-    for (int l = 0; l < a.n_enc; ++l) a.enc[l] = layer(m->enc[l], false);
-    for (int l = 0; l < a.n_dec; ++l) a.dec[l] = layer(m->dec[l], true);
+    std::vector<TLayer> tabs;
+    for (int l = 0; l < a.n_enc; ++l) tabs.push_back(layer(m->enc[l], false));
+    for (int l = 0; l < a.n_dec; ++l) tabs.push_back(layer(m->dec[l], true));
+    static_assert(sizeof(TLayer) % sizeof(float) == 0, "layer tables live in the float buffer");
+    a.enc_tab = (int)buf.size();
+    a.dec_tab = a.enc_tab + a.n_enc * (int)(sizeof(TLayer) / sizeof(float));
+    buf.resize(buf.size() + tabs.size() * sizeof(TLayer) / sizeof(float));
+    std::memcpy(buf.data() + a.enc_tab, tabs.data(), tabs.size() * sizeof(TLayer));
     if (null_seen) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: NULL tensor pointer in model");
 
     int ndev = 0;

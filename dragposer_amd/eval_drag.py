@@ -104,7 +104,7 @@ def run_sequences(args, seqs, opt, temporal_pack, cfg):
     tR = torch.stack([pad(q["tR"]) for q in seqs], dim=1).contiguous()
     gpos = torch.stack([pad(q["gpos"]) for q in seqs], dim=1).contiguous()      # [T, S, 3]
 
-    drag = DragPose(opt, temporal, means_latent, stds_latent, n_sequences=S)
+    drag = DragPose(opt, temporal, means_latent, stds_latent, n_sequences=S, native_temporal=not getattr(args, "torch_temporal", False))
     drag.set_initial_state(torch.cat([q["z0"] for q in seqs], dim=0), np.stack([q["m"]["global_pos"][0] for q in seqs]),
                            np.stack([q["m"]["global_rot"][0] for q in seqs]), np.stack([q["m"]["heights"][0] for q in seqs]))
     ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
@@ -166,6 +166,8 @@ def main(argv=None):
     ap.add_argument("input_path", help=".bvh file or a directory of .bvh files")
     ap.add_argument("--config", default=None, help="tracker config JSON (same keys as the reference's config/*.json)")
     ap.add_argument("--temporal-checkpoint", default=None, help="temporal.pt as saved by the reference's train_temporal.py")
+    ap.add_argument("--torch-temporal", action="store_true",
+                    help="run the temporal target block with PyTorch ops around nn.Transformer instead of dp_temporal_predict (one HIP launch)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--max-frames", type=int, default=None)
