@@ -15,8 +15,9 @@
 //     accumulator of the first product AS the A operand of the second -- register r of lane (token, q) holds hidden unit
 //     4q + r of the tile, which is K-slot q of K-step r by definition of the packed W2 image (12 MFMAs, no LDS, no
 //     transposition).  The tiles are dealt to the 8 waves, weights arrive as 7 coalesced 16-byte loads per lane and tile
-//     (four waves per SIMD cover their latency), the waves' partial outputs are summed through LDS.  fp32 throughout.
+//     (requested one tile ahead), the waves' partial outputs are summed through LDS.  fp32 throughout.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -91,11 +92,31 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
     __syncthreads();
 }
 
-DEV float wave_sum(float v)
+// Reductions over the 16 lanes of a DPP row (xor 1, xor 2, half mirror, mirror: every lane ends with the row's result) --
+// register-to-register, where __shfl_xor goes through the LDS crossbar (ds_bpermute: ~100 cycles a step)
+template <int CTRL> DEV float dpp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+DEV float row_sum(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v += dpp<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp<0x141>(v); // row_half_mirror
+    v += dpp<0x140>(v); // row_mirror
     return v;
+}
+DEV float row_max(float v)
+{
+    v = fmaxf(v, dpp<0xB1>(v));
+    v = fmaxf(v, dpp<0x4E>(v));
+    v = fmaxf(v, dpp<0x141>(v));
+    v = fmaxf(v, dpp<0x140>(v));
+    return v;
+}
+DEV float wave_sum(float v)
+{ // the four row sums through scalar reads
+    v = row_sum(v);
+    const int b = __float_as_int(v); // (the builtin reads an int: pass the bits, not the value)
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
 
 // x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm): one wave per token, one
@@ -117,34 +138,89 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
     __syncthreads();
 }
 
-// multi-head attention of Tq queries over Tk keys (no mask): ao[i][h*HD + c] = sum_j softmax_j(q_i . k_j / sqrt(HD)) v[j][h*HD + c]
+// q | k | v = in_proj(xq | xkv | xkv) in ONE phase: the nine 16-column tiles of the packed in_proj weight [48][144] (x token
+// tiles) are dealt to the waves; columns 0..47 take the query tokens, the rest the key / value tokens.
+DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* wT, const float* b)
+{
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (as in lin)
+    const int wave = threadIdx.x >> 6, l16 = lane & 15, qd = lane >> 4;
+    const int ttq = (Tq + 15) >> 4, ttk = (Tk + 15) >> 4, jobs = 3 * ttq + 6 * ttk;
+#pragma unroll 1
+    for (int job = wave; job < jobs; job += NWV) {
+        const bool isq = job < 3 * ttq;
+        const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : j2 / 6;
+        const float* in = isq ? xq : xkv;
+        const int T = isq ? Tq : Tk, n = 16 * nt + l16, t = 16 * tt + l16;
+        float bw[D / 4], av[D / 4];
+#pragma unroll
+        for (int ks = 0; ks < D / 4; ++ks) {
+            const int k = 4 * ks + qd;
+            bw[ks] = wT[k * 3 * D + n];
+            av[ks] = t < T ? in[t * D + k] : 0.f;
+        }
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int ks = 0; ks < D / 4; ks += 2) {
+            acc0 = mfma(av[ks], bw[ks], acc0);
+            acc1 = mfma(av[ks + 1], bw[ks + 1], acc1);
+        }
+        const float bias = b[n];
+        float* out = qkv + (n / D) * (MAXT * D) + (n % D); // q, k, v are consecutive [MAXT][D] arrays
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int to = 16 * tt + 4 * qd + r;
+            if (to < T) out[to * D] = acc0[r] + acc1[r] + bias;
+        }
+    }
+    __syncthreads();
+}
+
+// multi-head attention of Tq queries over Tk <= 32 keys (no mask), one wave per head, one phase:
+//   ao[i][h*HD + c] = sum_j softmax_j(q_i . k_j / sqrt(HD)) v[j][h*HD + c]
+// Lane (row r, j) -- r = lane / 16, j = lane % 16 -- holds keys j and j + 16; a turn of the loop takes four queries, one per
+// DPP row: 12-term dot products, the maximum and the sum over the keys by row reductions in registers, the probabilities
+// through this head's score rows in LDS (same wave: no barrier); then lane (query, channel) accumulates the output.
 DEV void attention(float* ao, const float* q, const float* k, const float* v, float* sc, int Tq, int Tk)
 {
-    const float scale = 1.f / sqrtf((float)HD);
-    for (int idx = threadIdx.x; idx < NHD * Tq * Tk; idx += NT) {
-        const int h = idx / (Tq * Tk), r = idx - h * Tq * Tk, i = r / Tk, j = r - i * Tk;
-        float acc = 0.f;
-        for (int c = 0; c < HD; ++c) acc = fmaf(q[i * D + h * HD + c], k[j * D + h * HD + c], acc);
-        sc[(h * MAXT + i) * MAXT + j] = acc * scale;
-    }
-    __syncthreads();
-    for (int row = threadIdx.x; row < NHD * Tq; row += NT) {
-        const int h = row / Tq, i = row - h * Tq;
-        float* p = sc + (h * MAXT + i) * MAXT;
-        float m = p[0];
-        for (int j = 1; j < Tk; ++j) m = fmaxf(m, p[j]);
-        float s = 0.f;
-        for (int j = 0; j < Tk; ++j) { const float e = expf(p[j] - m); p[j] = e; s += e; }
-        const float r = 1.f / s;
-        for (int j = 0; j < Tk; ++j) p[j] *= r;
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < Tq * D; idx += NT) {
-        const int i = idx / D, col = idx - i * D, h = col / HD;
-        const float* p = sc + (h * MAXT + i) * MAXT;
-        float acc = 0.f;
-        for (int j = 0; j < Tk; ++j) acc = fmaf(p[j], v[j * D + col], acc);
-        ao[i * D + col] = acc;
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    if (h < NHD) {
+        const float scale = 1.f / sqrtf((float)HD);
+        const int j = lane & 15, r = lane >> 4;
+        const bool live0 = j < Tk, live1 = j + 16 < Tk;
+        float k0[HD], k1[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            k0[c] = live0 ? k[j * D + h * HD + c] : 0.f;
+            k1[c] = live1 ? k[(j + 16) * D + h * HD + c] : 0.f;
+        }
+        float* sch = sc + h * MAXT * MAXT;
+#pragma unroll 1
+        for (int i0 = 0; i0 < Tq; i0 += 4) {
+            const int i = min(i0 + r, Tq - 1); // (a row beyond the last query recomputes it)
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) {
+                const float qc = q[i * D + h * HD + c];
+                s0 = fmaf(qc, k0[c], s0);
+                s1 = fmaf(qc, k1[c], s1);
+            }
+            s0 = live0 ? s0 * scale : -3.0e38f;
+            s1 = live1 ? s1 * scale : -3.0e38f;
+            const float m = row_max(fmaxf(s0, s1));
+            const float e0 = live0 ? expf(s0 - m) : 0.f, e1 = live1 ? expf(s1 - m) : 0.f;
+            const float inv = 1.f / row_sum(e0 + e1);
+            if (live0) sch[i * MAXT + j] = e0 * inv;
+            if (live1) sch[i * MAXT + j + 16] = e1 * inv;
+        }
+        // (LDS operations of a wave execute in order: the probabilities written above are visible below)
+        for (int idx = lane; idx < Tq * HD; idx += 64) {
+            const int i = idx / HD, c = idx - i * HD;
+            const float* p = sch + i * MAXT;
+            float acc = 0.f;
+            for (int jj = 0; jj < Tk; ++jj) acc = fmaf(p[jj], v[jj * D + h * HD + c], acc);
+            ao[i * D + h * HD + c] = acc;
+        }
     }
     __syncthreads();
 }
@@ -153,14 +229,42 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
 DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const float* w, int in_wT, int in_b, int out_wT, int out_b,
              float* q, float* k, float* v, float* ao, float* sc)
 {
-    lin<D / 4>(q, D, xq, D, Tq, w + in_wT, 3 * D, 0, w + in_b, D, D);
-    lin<D / 4>(k, D, xkv, D, Tk, w + in_wT, 3 * D, D, w + in_b, D, D);
-    lin<D / 4>(v, D, xkv, D, Tk, w + in_wT, 3 * D, 2 * D, w + in_b, D, D);
+    lin_qkv(q, xq, Tq, xkv, Tk, w + in_wT, w + in_b);
     attention(ao, q, k, v, sc, Tq, Tk);
     lin<D / 4>(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
 }
 
-// o[t] = linear2(relu(linear1(x[t]))) + bias2  (header comment; pack layout in dp_temporal_create)
+// one tile of 16 hidden units: H^T = W1 X^T (12 MFMAs), bias + ReLU, OUT += H W2^T (12 MFMAs; the first product's
+// accumulator is the second's A operand)
+DEV void ffn_tile(const f4 (&im)[7], const float (&xb)[D / 4], f4 (&acc)[3])
+{
+    f4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+#pragma unroll
+    for (int ks = 0; ks < D / 4; ks += 2) {
+        h0 = mfma(im[ks >> 2][ks & 3], xb[ks], h0);
+        h1 = mfma(im[(ks + 1) >> 2][(ks + 1) & 3], xb[ks + 1], h1);
+    }
+    f4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = fmaxf(h0[r] + h1[r] + im[6][r], 0.f); // hidden unit 16 nt + 4 q + r, token l16
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) { const int i = 3 * r + ct; acc[ct] = mfma(h[r], im[3 + (i >> 2)][i & 3], acc[ct]); }
+    }
+}
+DEV void ffn_load(f4 (&im)[7], const f4* img, int nt, int ntiles)
+{
+    if (nt < ntiles) {
+#pragma unroll
+        for (int v = 0; v < 7; ++v) im[v] = img[((size_t)nt * 7 + v) * 64];
+    }
+}
+
+// o[t] = linear2(relu(linear1(x[t]))) + bias2  (header comment; pack layout in dp_temporal_create).
+// PREFETCH: a wave keeps the images of three tiles in flight (84 registers: the one-workgroup-per-CU kernel, where a SIMD
+// has two waves to hide an L2 round trip behind 768 cycles of MFMA per tile); otherwise one, and four waves per SIMD.
+template <bool PREFETCH>
 DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red)
 {
     int lane = threadIdx.x & 63;
@@ -175,26 +279,24 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 #pragma unroll
         for (int ks = 0; ks < D / 4; ++ks) xb[ks] = t < T ? x[t * D + 4 * ks + q] : 0.f;
         f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // (no software prefetch: with four waves per SIMD the other waves cover the load latency, and the registers of a
-        //  second tile image would not fit the 128 a wave has at that occupancy)
-#pragma unroll 1
-        for (int nt = wave; nt < ntiles; nt += NWV) {
-            f4 cur[7];
-#pragma unroll
-            for (int v = 0; v < 7; ++v) cur[v] = img[((size_t)nt * 7 + v) * 64];
-            f4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
-#pragma unroll
-            for (int ks = 0; ks < D / 4; ks += 2) {
-                h0 = mfma(cur[ks >> 2][ks & 3], xb[ks], h0);
-                h1 = mfma(cur[(ks + 1) >> 2][(ks + 1) & 3], xb[ks + 1], h1);
+        if (PREFETCH) {
+            f4 b0[7], b1[7], b2[7];
+            int nt = wave;
+            ffn_load(b0, img, nt, ntiles);
+            ffn_load(b1, img, nt + NWV, ntiles);
+            while (nt < ntiles) {
+                ffn_load(b2, img, nt + 2 * NWV, ntiles); ffn_tile(b0, xb, acc); nt += NWV;
+                if (nt >= ntiles) break;
+                ffn_load(b0, img, nt + 2 * NWV, ntiles); ffn_tile(b1, xb, acc); nt += NWV;
+                if (nt >= ntiles) break;
+                ffn_load(b1, img, nt + 2 * NWV, ntiles); ffn_tile(b2, xb, acc); nt += NWV;
             }
-            f4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = fmaxf(h0[r] + h1[r] + cur[6][r], 0.f); // hidden unit 16 nt + 4 q + r, token l16
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) { const int i = 3 * r + ct; acc[ct] = mfma(h[r], cur[3 + (i >> 2)][i & 3], acc[ct]); }
+        } else {
+#pragma unroll 1
+            for (int nt = wave; nt < ntiles; nt += NWV) {
+                f4 cur[7];
+                ffn_load(cur, img, nt, ntiles);
+                ffn_tile(cur, xb, acc);
             }
         }
         // the waves' partial outputs: lane (channel l16 of tile ct, token group q), register r = token 4 q + r
@@ -215,7 +317,10 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
     }
 }
 
-__global__ __launch_bounds__(NT, 4) void dp_temporal_kernel(const TArgs a) // (4 waves per SIMD = two workgroups per CU)
+// OCC = waves per SIMD: 4 (two workgroups per CU, 128 registers: throughput with many sequences) or 2 (one workgroup per CU,
+// 256 registers, feed-forward weights prefetched three tiles deep: latency with few)
+template <int OCC>
+__global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
 {
     __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D];
     // q, k, v and the attention output; dead while the feed-forward block runs, whose cross-wave reduction buffer is the
@@ -249,7 +354,7 @@ __global__ __launch_bounds__(NT, 4) void dp_temporal_kernel(const TArgs a) // (4
         const TLayer L = ((const TLayer*)(w + a.enc_tab))[l];
         mha(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln(x, o, Te, w + L.n1w, w + L.n1b);
-        ffn(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
+        ffn<OCC == 2>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
         add_ln(x, o, Te, w + L.n2w, w + L.n2b);
     }
     add_ln(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
@@ -266,7 +371,7 @@ __global__ __launch_bounds__(NT, 4) void dp_temporal_kernel(const TArgs a) // (4
             add_ln(x, o, T, w + L.n1w, w + L.n1b);
             mha(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
             add_ln(x, o, T, w + L.n2w, w + L.n2b);
-            ffn(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
+            ffn<OCC == 2>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
             add_ln(x, o, T, w + L.n3w, w + L.n3b);
         }
         add_ln(x, nullptr, T, w + a.decn_w, w + a.decn_b);
@@ -289,7 +394,8 @@ thread_local std::string g_terr;
 } // namespace
 
 struct dp_temporal {
-    int device = -1;
+    int device = -1, n_cu = 256;
+    int forced_occ = 0; // DP_TEMPORAL_OCC in the environment at dp_temporal_create: 2 or 4 = that kernel variant whatever the batch (tests)
     float* d_w = nullptr;
     TArgs args{};
     std::string err;
@@ -404,6 +510,8 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, DP_ERR_DEVICE, "dp_temporal_create: hipSetDevice failed");
     dp_temporal* t = new dp_temporal;
     t->device = device;
+    if (const char* e = std::getenv("DP_TEMPORAL_OCC")) t->forced_occ = std::atoi(e) == 2 ? 2 : (std::atoi(e) == 4 ? 4 : 0);
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->n_cu = cu; }
     hipError_t e = hipMalloc((void**)&t->d_w, buf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->d_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice);
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
@@ -447,7 +555,9 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     TArgs a = m;
     a.latent_buf = st->latent_buf; a.disp_buf = st->disp_buf; a.heights_buf = st->heights_buf;
     a.H = st->history; a.n_seq = n_seq; a.window = window; a.target = target_buf;
-    hipLaunchKernelGGL(dp_temporal_kernel, dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    const bool few = t->forced_occ ? t->forced_occ == 2 : n_seq <= t->n_cu;
+    if (few) hipLaunchKernelGGL(dp_temporal_kernel<2>, dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(dp_temporal_kernel<4>, dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return tfail(t, DP_ERR_LAUNCH, std::string("dp_temporal_predict: ") + hipGetErrorString(e));

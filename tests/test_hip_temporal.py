@@ -35,9 +35,12 @@ def _torch_block(model, means, stds, lat, disp, hts, window):
     return buf
 
 
+@pytest.mark.parametrize("occ", [2, 4])  # the two kernel variants: one workgroup per CU with prefetch (few sequences) / two per CU
 @pytest.mark.parametrize("window", [0, 16, 60])
-def test_native_predictor_matches_nn_transformer_at_full_size(window):
+def test_native_predictor_matches_nn_transformer_at_full_size(window, occ, monkeypatch):
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+    monkeypatch.setenv("DP_TEMPORAL_OCC", str(occ))  # read at dp_temporal_create
 
     torch.manual_seed(3)
     model = TemporalPredictor().eval()  # 3 + 3 layers, d_model 48, 4 heads, feed-forward 2048 (train_temporal.py:17-37)
@@ -53,7 +56,7 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window):
     got = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
     assert got.shape == (S, window + 1, 24)
     err = (got - want).abs().max().item()
-    print(f"window {window}: max |native - nn.Transformer| = {err:.2e} (targets of magnitude {want.abs().max().item():.2f})")
+    print(f"window {window}, variant {occ}: max |native - nn.Transformer| = {err:.2e} (targets of magnitude {want.abs().max().item():.2f})")
     # fp32 against fp32 in a different summation order through 6 LayerNorm-ed layers and up to 16 autoregressive calls
     assert err <= 1e-5, err
 
