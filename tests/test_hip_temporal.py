@@ -61,6 +61,29 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window, occ, monke
     assert err <= 1e-5, err
 
 
+@pytest.mark.parametrize("occ", [2, 4])
+def test_more_than_sixteen_tokens_take_two_tiles(occ, monkeypatch):
+    """window 100 = 26 autoregressive calls, the last ones over 17..26 target tokens: two 16-token tiles in every product,
+    keys beyond 16 in the attention; a feed-forward width that is not a multiple of 16 (zero-padded tile)."""
+    from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+    monkeypatch.setenv("DP_TEMPORAL_OCC", str(occ))
+    torch.manual_seed(5)
+    model = TemporalPredictor(n_encoder_layers=2, n_decoder_layers=2, dim_feedforward=200).eval()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(12)
+    S, H, window = 3, 60, 100
+    means, stds = 0.2 * torch.randn(24, generator=g), 0.5 + torch.rand(24, generator=g)
+    lat, disp, hts = torch.randn(S, H, 24, generator=g), 0.02 * torch.randn(S, H, 3, generator=g), 1.0 + 0.3 * torch.randn(S, H, 6, generator=g)
+    want = _torch_block(model, means, stds, lat, disp, hts, window)
+    got = NativeTemporal(model, means, stds, device="cuda:0").predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
+    err = (got - want).abs().max().item()
+    print(f"window {window}, variant {occ}: max |native - nn.Transformer| = {err:.2e}")
+    assert err <= 2e-5, err
+
+
 @pytest.mark.parametrize("name", ["seq6", "seq3"])
 def test_native_predictor_reproduces_the_reference_targets(golden_dir, name):
     """Closed loop over the reference-recorded sequences with the native predictor in the operator: the `z_tgt` it hands the

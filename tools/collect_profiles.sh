@@ -35,4 +35,9 @@ for mode in "--frames 4096" "--total-frames 4096" "--total-frames 8192"; do
       --backend gloo --all-ranks-on-device0 --no-cpu-baseline $mode 2>/dev/null | tail -1
 done > $O/rehearsal_2ranks_gloo_one_gpu.jsonl
 echo "rehearsal done"
+# 7. the temporal predictor: times against PyTorch ops, and the kernel trace of its launches alone
+python3 tools/time_temporal.py 2>&1 | grep "^window" > $O/temporal_predictor_times.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tstats --output-format csv -- python3 tools/time_temporal.py --native-only > $O/tstats.log 2>&1
+grep "dp_temporal_kernel\|\"Name\"" $(find $O/tstats -name "*kernel_stats.csv" | head -1) > $O/temporal_kernel_stats.csv
+echo "temporal done"
 ls $O

@@ -28,12 +28,13 @@ def torch_block(lat, disp, hts, window, step=4):
     return buf
 
 
+NATIVE_ONLY = "--native-only" in sys.argv  # (for rocprofv3 --kernel-trace --stats: only dp_temporal_kernel launches)
 for window in (0, 16, 60):
     for S in (1, 64, 256, 1024, 4096):
         lat, disp, hts = torch.randn(S, 60, 24, device=dev), torch.randn(S, 60, 3, device=dev), torch.randn(S, 60, 6, device=dev)
         out = torch.empty(S, window + 1, 24, device=dev)
         res = []
-        for fn in (lambda: nat.predict(lat, disp, hts, window, out=out), lambda: torch_block(lat, disp, hts, window)):
+        for fn in (lambda: nat.predict(lat, disp, hts, window, out=out), lambda: torch_block(lat, disp, hts, window))[:1 if NATIVE_ONLY else 2]:
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
@@ -44,4 +45,4 @@ for window in (0, 16, 60):
                 fn()
             e1.record(); e1.synchronize()
             res.append(e0.elapsed_time(e1) / n)
-        print(f"window {window:2d} S={S:5d}: native {res[0]:9.3f} ms   torch ops {res[1]:9.3f} ms", flush=True)
+        print(f"window {window:2d} S={S:5d}: native {res[0]:9.3f} ms" + ("" if NATIVE_ONLY else f"   torch ops {res[1]:9.3f} ms"), flush=True)
