@@ -187,6 +187,30 @@ DEV void quad_transpose_mfma(f4& r, const f4& e)
     r = d;
 }
 #define QT(x) quad_transpose_mfma(x, eT)
+// two independent transposes, their dependent chains interleaved (a dependent 2-pass MFMA needs 2 wait states: the other
+// chain's MFMA and one s_nop)
+DEV void quad_transpose_mfma2(f4& r0, f4& r1, const f4& e)
+{
+    f4 d0, d1;
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %2, %10, 0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %6, %10, 0\n\t"
+                 "s_nop 0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %3, %11, %0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %7, %11, %1\n\t"
+                 "s_nop 0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %4, %12, %0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %8, %12, %1\n\t"
+                 "s_nop 0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %0, %5, %13, %0\n\t"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %9, %13, %1\n\t"
+                 "s_nop 3"
+                 : "=&v"(d0), "=&v"(d1)
+                 : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]), "v"(e[0]), "v"(e[1]),
+                   "v"(e[2]), "v"(e[3]));
+    r0 = d0;
+    r1 = d1;
+}
 
 DEV f4 splat(float v) { return f4{v, v, v, v}; }
 // LeakyReLU(0.2) as a per-element factor (1 or 0.2): forward a = x * f, backward d = g * f -- the factor is what the
@@ -797,8 +821,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             y01 = pa0 + pa1;
             y23 = pb0 + pb1;
         }
-        QT(y01); // lane (b, i): the decoder channels of my two items of frame i, side A | side B in register pairs
-        QT(y23);
+        __builtin_amdgcn_sched_barrier(0); // (both sums first: a VALU instruction between two MFMAs of one wave costs ~14 cycles)
+        quad_transpose_mfma2(y01, y23, eT); // lane (b, i): the decoder channels of my two items of frame i, side A | side B in register pairs
         STAMP(2);
 
         // ================= kinematics
@@ -872,6 +896,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         chain_begin();
         chain3_v_zero<5>(acc0, acc1, x, wz); // two K-steps per instruction: lanes 0..31 | 32..63 hold the two halves of the sum
         chain_end(acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0); // (keeps the subtraction below out of the chains above: w4_probe, "independent v_pk_fma")
         const f4 g = add_halves(acc0 + acc1) + a.ctmp * (zD - ztD);
         STAMP(8);
         if (DBG_DUMP && a.dbg && iter == 0 && lane < LAT) {

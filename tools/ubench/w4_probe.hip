@@ -115,6 +115,36 @@ template <int NACC> __global__ __launch_bounds__(256, 1) void k_bf16_rate(float*
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
+// ---------------------------------------------------------------- 2c. can the VALU run under the matrix pipe?  One wave per SIMD:
+// a chain of 4x4x1 MFMAs on two accumulators with NV independent v_pk_fma_f32 (four separate dependency chains) issued
+// behind every MFMA -- the question behind software-pipelining two frame groups in one wave
+template <int ABID> DEV void ov_mfma(f4& acc, float x, float w) { asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:4 abid:%3" : "+v"(acc) : "v"(x), "v"(w), "i"(ABID)); }
+DEV void ov_valu(f2& v, f2 m, f2 c) { asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(m), "v"(c)); }
+template <int NV> __global__ __launch_bounds__(256, 1) void k_overlap(float* out, int iters, unsigned long long* cyc)
+{
+    const int l = threadIdx.x & 63;
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    float x = 1.f + l, w0 = 1e-3f * l, w1 = 2e-3f * l;
+    f2 v[4] = {{1.f, 2.f}, {3.f, 4.f}, {5.f, 6.f}, {7.f, 8.f}};
+    const f2 m = {1.0001f, 0.9999f}, c = {1e-3f, -1e-3f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        static_for<48>([&](auto ki) {
+            constexpr int k = decltype(ki)::value;
+            ov_mfma<(k & 15)>(acc0, x, w0);
+            if constexpr (NV >= 1) ov_valu(v[0], m, c);
+            if constexpr (NV >= 2) ov_valu(v[1], m, c);
+            ov_mfma<(k & 15)>(acc1, x, w1);
+            if constexpr (NV >= 1) ov_valu(v[2], m, c);
+            if constexpr (NV >= 2) ov_valu(v[3], m, c);
+        });
+        x += acc0[0] * 1e-30f;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc0[0] + acc1[1] + v[0].x + v[1].y + v[2].x + v[3].y;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
 // ---------------------------------------------------------------- 3. VALU issue: scalar vs packed fp32
 template <int MODE, int ILP> __global__ void k_valu(float* out, int iters, unsigned long long* cyc)
 {
@@ -278,6 +308,13 @@ int main()
     hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);                                                                           \
     printf("mfma 4x4x4 bf16 (K = 4): %d acc, %d blocks x %d waves: %.2f cycles per MFMA\n", NACC, BLOCKS, THREADS / 64, (double)h / (iters * 96.0));
     RUN_BF16(1, 1, 64) RUN_BF16(2, 1, 64) RUN_BF16(2, 256, 256) RUN_BF16(4, 256, 256)
+
+#define RUN_OVL(NV)                                                                                                         \
+    hipLaunchKernelGGL((k_overlap<NV>), dim3(256), dim3(256), 0, 0, out, iters, cyc);                                       \
+    hipDeviceSynchronize();                                                                                                 \
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);                                                                           \
+    printf("mfma 4x4x1 chain with %d independent v_pk_fma_f32 behind every MFMA (256 blocks x 4 waves): %.2f cycles per MFMA\n", NV, (double)h / (iters * 96.0));
+    RUN_OVL(0) RUN_OVL(1) RUN_OVL(2)
 
     const int vit = 2000;
     const char* names[5] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_mul_f32"};
