@@ -97,7 +97,11 @@ typedef struct dp_batch {
     const float* z_tgt;   /* [B][24] temporal prediction (target_latent, drag_pose.py:294) */
     const float* cur_rot; /* [B][4]  current_global_rot */
     const float* tgt_pos; /* [B][22][3] target_ee_pos scattered to joint slots */
-    const float* tgt_rot; /* [B][22][9] target_ee_rot (row-major 3x3) scattered to joint slots */
+    const float* tgt_rot; /* [B][22][9] target_ee_rot (row-major 3x3) scattered to joint slots.  Must be ROTATION matrices
+                             (orthonormal, det +1) -- what the reference's callers pass (eval_drag.py:186-199 from FK,
+                             run_drag.py:136 from quaternions): the kernel turns each into a quaternion once per launch and
+                             evaluates |R - T|_F^2 as 8 |vec(conj(q_R) q_T)|^2, which equals the reference's element-wise
+                             form only for rotations */
     const float* w;       /* [B][22][2] */
     const unsigned char* tracked; /* [B][22] */
 } dp_batch;
