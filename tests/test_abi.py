@@ -115,3 +115,30 @@ def test_skeleton_limits_are_reported():
     assert rc_of(chain) == _lib.DP_ERR_UNSUPPORTED and "7 bones" in _lib.last_error()
     fan = np.array([0, 0] + [1] * 20, np.int32)  # joint 1 with 20 children
     assert rc_of(fan) == _lib.DP_ERR_UNSUPPORTED and "extra child" in _lib.last_error()
+
+
+def test_temporal_predictor_argument_checks_and_no_cpu_fallback():
+    """dp_temporal_create validates the model before it touches a device, and -- like dp_create -- has no CPU path."""
+    import torch
+
+    from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.dp_temporal_create(C.byref(h), None, 0) == _lib.DP_ERR_INVALID and not h.value
+    assert b"model is NULL" in lib.dp_temporal_last_error(None)
+    m = _lib.DpTemporalModel()
+    m.n_heights, m.dim_feedforward, m.n_encoder_layers, m.n_decoder_layers, m.max_len, m.sample_step = 6, 32, 9, 1, 30, 4
+    assert lib.dp_temporal_create(C.byref(h), C.byref(m), 0) == _lib.DP_ERR_INVALID  # more than DP_TEMPORAL_MAX_LAYERS
+    m.n_encoder_layers = 1
+    assert lib.dp_temporal_create(C.byref(h), C.byref(m), 0) == _lib.DP_ERR_INVALID  # tensor pointers are NULL
+    assert b"NULL" in lib.dp_temporal_last_error(None)
+    assert lib.dp_temporal_destroy(None) == _lib.DP_ERR_INVALID
+    torch.manual_seed(0)
+    model = TemporalPredictor(n_encoder_layers=1, n_decoder_layers=1, dim_feedforward=32).eval()
+    if not HAS_GPU:
+        with pytest.raises(ValueError):
+            NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cpu")
+        with pytest.raises(Exception) as e:  # a well-formed model, no device: refused, not emulated
+            NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+        assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
