@@ -47,7 +47,8 @@ constexpr int FB_ZPRE = FB_TI + 12 * W4_R;   // [24] latent of the last forward 
 constexpr int FB_ZT = FB_ZPRE + LAT;         // [24] z_tgt (epilogue only)
 constexpr int FB_LT = FB_ZT + LAT;           // [24] early stop: (z - z_tgt)^2 per latent dim of the current latent
 constexpr int FB_ES = FB_LT + LAT;           // [4]  early stop: losses of the frame's last executed iteration (pos, rot, tmp, -)
-constexpr int FB_END = FB_ES + 4;
+constexpr int FB_CUR = FB_ES + 4;            // [4]  cur_rot of the frame (for the epilogue)
+constexpr int FB_END = FB_CUR + 4;
 constexpr int QS_DISP = ITEM_DISP, QS_IDENT = 30, QS_TRASH = 31, WT_ZERO = 30, WT_TRASH = 31;
 // the four frames of a wave sit in the four lanes of every quad: block stride = 16 banks (mod 64) apart, so that the
 // quad's 16-byte accesses to the same row of four blocks never share a bank
@@ -57,7 +58,8 @@ static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && F
 constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26;     // the streamed product: first group, groups
 constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
 constexpr int L_TAB = L_IMG2 + NG_B2 * 256;     // per-iteration Adam scalars [MAX_ITERS][2]: step, 1/sqrt(1-beta2^t)
-constexpr int L_FR = L_TAB + 2 * MAX_ITERS;     // frame blocks [NW * 4][FB_STRIDE]
+constexpr int L_OC = L_TAB + 2 * MAX_ITERS;     // [16 quads][20] what the epilogue needs per quad: sd[4][2], mu[4][2], path words of both items
+constexpr int L_FR = L_OC + 16 * 20;            // frame blocks [NW * 4][FB_STRIDE]
 template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE; }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,18 +529,16 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
 // ---- outputs of the LAST forward pass of (item, frame gf) from the frame block (reference: drag_pose.py:84-113 and what
 // run() returns); kept simple, it runs once
 struct OutC { int item, kind; f4 sd, mu; unsigned plo, phi; }; // what an item's outputs need from global memory
-DEV void out_consts(const KArgs& a, const Pair* pp, int itemA, int kindA, int itemB, int kindB, OutC& oA, OutC& oB)
-{ // every load of the epilogue, issued together (one round trip instead of one per item and table)
-    const f4* t = (const f4*)pp; // sd[4][2], mu[4][2]: the two sides interleaved
-    const f4 s0 = t[0], s1 = t[1], m0 = t[2], m1 = t[3];
+DEV void out_consts(const float* oc, int itemA, int kindA, int itemB, int kindB, OutC& oA, OutC& oB)
+{ // from the quad's row of L_OC (staged by the set-up: no global round trip between the last iteration and the stores)
+    const f4* t = (const f4*)oc; // sd[4][2], mu[4][2]: the two sides interleaved; then path_lo/hi of side A, of side B
+    const f4 s0 = t[0], s1 = t[1], m0 = t[2], m1 = t[3], pw = t[4];
     oA.item = itemA; oA.kind = kindA;
     oB.item = itemB; oB.kind = kindB;
     oA.sd = f4{s0.x, s0.z, s1.x, s1.z}; oB.sd = f4{s0.y, s0.w, s1.y, s1.w};
     oA.mu = f4{m0.x, m0.z, m1.x, m1.z}; oB.mu = f4{m0.y, m0.w, m1.y, m1.w};
-    const ItemConst* ia = a.items + max(itemA, 0);
-    const ItemConst* ib = a.items + max(itemB, 0);
-    oA.plo = ia->path_lo; oA.phi = ia->path_hi;
-    oB.plo = ib->path_lo; oB.phi = ib->path_hi;
+    oA.plo = __float_as_uint(pw.x); oA.phi = __float_as_uint(pw.y);
+    oB.plo = __float_as_uint(pw.z); oB.phi = __float_as_uint(pw.w);
 }
 DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
 {
@@ -682,6 +682,17 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const ItemConst* ic = a.items + min(b, MAX_ROOT_CH - 1); // constant root-frame bones of the root's children (quads 0..2 store them)
     const int init_id = ic->init_id;
     const f4 init_off = {ic->init_off[0], ic->init_off[1], ic->init_off[2], 0.f};
+    // what the epilogue will need per quad (wave 0, one lane per quad): parked in LDS now, while loads are cheap
+    const bool oc_lane = wave == 0 && i == 0;
+    f4 ocv[5] = {};
+    if (oc_lane) {
+        const f4* t = (const f4*)pp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ocv[k] = t[k];
+        const ItemConst* ia = a.items + item_of(0, b); // (the item ids of a quad are a function of b: no dependent load)
+        const ItemConst* ib = a.items + max(item_of(1, b), 0);
+        ocv[4] = f4{__uint_as_float(ia->path_lo), __uint_as_float(ia->path_hi), __uint_as_float(ib->path_lo), __uint_as_float(ib->path_hi)};
+    }
     const f2 adam_row = tid < a.n_iter ? f2{a.tab.step[tid], a.tab.bc2s[tid]} : f2{0.f, 0.f}; // (n_iter <= 256 = one row per thread)
     __builtin_amdgcn_sched_barrier(0);
 
@@ -733,6 +744,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     }
     static_assert(MAX_ITERS <= NW * 64, "one row of the Adam table per thread");
     if (tid < a.n_iter) *(f2*)(lds + L_TAB + 2 * tid) = adam_row;
+    if (oc_lane) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) *(f4*)(lds + L_OC + 20 * b + 4 * k) = ocv[k];
+    }
+    if (b == 0) *(f4*)(fb + FB_CUR) = cv;
     wave_sync(); // (the zero fill above and the tracker records below touch the same frame blocks from different lanes)
 
     pc.qsA = FB_QS + 4 * pc.itemA;
@@ -972,9 +988,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     }
     wave_sync();
     {
-        const f4 cve = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
+        const f4 cve = *(const f4*)(fb + FB_CUR);
         OutC oA, oB;
-        out_consts(a, pp, pc.itemA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, pc.itemB, pc.kindB, oA, oB);
+        out_consts(lds + L_OC + 20 * b, pc.itemA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, pc.itemB, pc.kindB, oA, oB);
         if (fvalid) {
             const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
             w4_outputs(a, oA, fb, gfi, optimise, cur, tmask, EARLY);
