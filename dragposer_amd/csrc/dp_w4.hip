@@ -642,11 +642,23 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     float* fb0 = lds + L_FR + wave * FPW * FB_STRIDE; // this wave's four frame blocks
     float* fb = fb0 + i * FB_STRIDE;
 
-    // ---- The setup is a chain of dependent global round trips (tracked flags -> which joints -> their targets) beside one
-    //      long stream (the resident weights, 73 KB per wave).  Loads of a wave complete in issue order and issuing blocks
-    //      once the memory pipeline is full, so the order of ISSUE below is: the small first-level loads; half of the
-    //      stream (the first level comes back while it drains); the trackers' second-level loads; the other half (the
-    //      second level comes back under it); then the arithmetic on what has arrived.
+    // ---- Set-up.  Two things have to arrive: per wave, 71 KB of resident weights (the same for every wave), and a chain of
+    //      dependent global round trips (tracked flags -> which joints -> their targets).  A wave may have 63 vector loads
+    //      outstanding (vmcnt), so 71 weight loads per lane block it, and four waves pulling the same 71 KB through one
+    //      64 B/clk L1 take 4.6 k cycles.  Instead the workgroup fetches the weight image ONCE -- 23 loads per lane into LDS
+    //      (over the area the frame blocks will occupy; the streamed part straight to its final place) -- and every wave
+    //      fills its registers from LDS (128 B/clk) while its tracker loads are in flight.  Three barriers instead of one.
+    // ---- the whole weight image, once per workgroup: global -> registers -> LDS, requested before anything else (it is what
+    //      the longest part of the set-up -- filling the registers -- waits for).  Groups of the streamed product (bL2) go to
+    //      L_IMG2, where they stay; the others to the staging area [L_TAB, ...), in image order without them.
+    constexpr int N_IMG = N_GROUPS * 64, N_LD = (N_IMG + NW * 64 - 1) / (NW * 64); // float4s of the image, loads per thread
+    static_assert((N_GROUPS - NG_B2) * 256 <= lds_total<NW>() - L_TAB, "the staging area holds the resident groups");
+    f4 im[N_LD];
+#pragma unroll
+    for (int k = 0; k < N_LD; ++k)
+        if (tid + k * NW * 64 < N_IMG) im[k] = ((const f4*)a.w4img)[tid + k * NW * 64];
+    __builtin_amdgcn_sched_barrier(0);
+
     // (dp_forward has no trackers and passes no tracker arrays: the loads then read the weight image and are ignored)
     typedef unsigned u32_any __attribute__((aligned(1), may_alias));
     typedef unsigned short u16_any __attribute__((aligned(1), may_alias));
@@ -696,24 +708,31 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const f2 adam_row = tid < a.n_iter ? f2{a.tab.step[tid], a.tab.bc2s[tid]} : f2{0.f, 0.f}; // (n_iter <= 256 = one row per thread)
     __builtin_amdgcn_sched_barrier(0);
 
-    // the streamed weight image (bL2), on its way into LDS (the only data the waves of a workgroup share), and the first half
-    // of the resident weight images: 66 loads per lane from the (L2-resident) global image.  (MFMA B operands,
-    // loop-invariant: L0, L1, L2A, L2B, bL1 = 61 groups = 244 accumulator registers; bL0's 5 groups in VECTOR registers --
-    // measured +2 % over streaming them; the accumulator half is full.)  Issuing them BLOCKS the wave for as long as the
-    // stream takes to drain into the memory pipeline -- which is time the first-level loads need anyway.
-    constexpr int N_ST = (NG_B2 * 64 + NW * 64 - 1) / (NW * 64);
-    f4 st[N_ST];
+    // the image into LDS (the small loads above stay in flight: loads return in issue order and the image came first)
 #pragma unroll
-    for (int k = 0; k < N_ST; ++k)
-        if (tid + k * NW * 64 < NG_B2 * 64) st[k] = ((const f4*)a.w4img)[GR_B2 * 64 + tid + k * NW * 64];
+    for (int k = 0; k < N_LD; ++k) {
+        const int e = tid + k * NW * 64, g = e >> 6; // float4 index, group
+        if (e < N_IMG) {
+            const int dst = g < GR_B2 ? L_TAB + 4 * e : g < GR_B2 + NG_B2 ? L_IMG2 + 4 * (e - GR_B2 * 64) : L_TAB + 4 * (e - NG_B2 * 64);
+            *(f4*)(lds + dst) = im[k];
+        }
+    }
+    __syncthreads();
+
+    // resident weights from the staging area (MFMA B operands, loop-invariant: L0, L1, L2A, L2B, bL1 = 61 groups = 244
+    // accumulator registers; bL0's 5 groups in VECTOR registers -- measured +2 % over streaming them; the head of bL2 in
+    // what is left of both halves).  First the forward layers (the small loads have that long to come back) ...
     f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15], wz[5];
-    const f4* wimg = (const f4*)a.w4img + lane;
-    load_w<6>(wL0, wimg + (S_L0 / 4) * 64);
-    load_w<10>(wL1, wimg + (S_L1 / 4) * 64);
-    load_w<15>(wL2A, wimg + (S_L2A / 4) * 64);
+    constexpr int B2_RES_A = W4_B2_RES_A, B2_RES_V = EARLY ? 0 : W4_B2_RES_V, B2_RES = B2_RES_A + B2_RES_V;
+    f4 wB2a[B2_RES_A > 0 ? B2_RES_A : 1], wB2v[B2_RES_V > 0 ? B2_RES_V : 1];
+    const f4* wst = (const f4*)(lds + L_TAB) + lane; // group g of the image at wst[64 g] (g < GR_B2), wst[64 (g - NG_B2)] beyond bL2
+    load_w<6>(wL0, wst + (S_L0 / 4) * 64);
+    load_w<10>(wL1, wst + (S_L1 / 4) * 64);
+    load_w<15>(wL2A, wst + (S_L2A / 4) * 64);
+    load_w<15>(wL2B, wst + (S_L2B / 4) * 64);
     __builtin_amdgcn_sched_barrier(0);
 
-    // second level, in the middle of the stream: the trackers of my frame (lane 4u+i: rank u of frame i)
+    // ... then the second level of the tracker chain (lane 4u+i: rank u of frame i), in flight under the rest
     unsigned tmask = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) tmask |= (((tflag[j >> 2] >> (8 * (j & 3))) & 0xffu) ? 1u : 0u) << j;
@@ -725,14 +744,16 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SETUP_STAMP(0);
     __builtin_amdgcn_sched_barrier(0);
 
-    load_w<15>(wL2B, wimg + (S_L2B / 4) * 64);
-    load_w<15>(wB1, wimg + (S_B1 / 4) * 64);
-    load_w<5>(wz, wimg + (S_B0 / 4) * 64);
-    constexpr int B2_RES_A = W4_B2_RES_A, B2_RES_V = EARLY ? 0 : W4_B2_RES_V, B2_RES = B2_RES_A + B2_RES_V;
-    f4 wB2a[B2_RES_A > 0 ? B2_RES_A : 1], wB2v[B2_RES_V > 0 ? B2_RES_V : 1]; // the head of bL2 (above)
-    load_w<B2_RES_A>(wB2a, wimg + (S_B2 / 4) * 64);
-    load_w<B2_RES_V>(wB2v, wimg + (S_B2 / 4 + B2_RES_A) * 64);
-    __builtin_amdgcn_sched_barrier(0);
+    load_w<15>(wB1, wst + (S_B1 / 4 - NG_B2) * 64);
+    load_w<5>(wz, wst + (S_B0 / 4 - NG_B2) * 64);
+    {
+        const f4* w2 = (const f4*)(lds + L_IMG2) + lane;
+        load_w<B2_RES_A>(wB2a, w2);
+        load_w<B2_RES_V>(wB2v, w2 + B2_RES_A * 64);
+    }
+    touch_a<6>(wL0); touch_a<10>(wL1); touch_a<15>(wL2A); touch_a<15>(wL2B); touch_a<15>(wB1);
+    touch_a<B2_RES_A>(wB2a); touch_v<B2_RES_V>(wB2v); touch_v<5>(wz); // (the reads have completed: the area is free)
+    __syncthreads();
 
     // ---- under the stream: frame blocks, trackers, LDS image
     // what has to read as zero in a frame block: the own-torque slots of untracked joints, the two tracker tables (stage G
@@ -786,19 +807,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         for (int r = 0; r < FPW; ++r) { const float dz = zD[r] - ztD[r]; fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz; }
     }
 
-#pragma unroll
-    for (int k = 0; k < N_ST; ++k)
-        if (tid + k * NW * 64 < NG_B2 * 64) ((f4*)(lds + L_IMG2))[tid + k * NW * 64] = st[k];
     __syncthreads();
     if (f0 >= nB) return; // (uniform per wave) no barrier below this line
 
     SETUP_STAMP(2);
     wave_sync();
 
-    // every resident weight is "used" here, once: the waits for their loads then stand in front of the loop instead of in
-    // front of each weight's first use inside it (22 s_waitcnt vmcnt per iteration otherwise; no instruction is emitted)
-    touch_a<6>(wL0); touch_a<10>(wL1); touch_a<15>(wL2A); touch_a<15>(wL2B); touch_a<15>(wB1);
-    touch_a<B2_RES_A>(wB2a); touch_v<B2_RES_V>(wB2v); touch_v<5>(wz);
     const f4 bias0T = splat(bias0), bias1T = splat(bias1), bias2aT = splat(bias2a), bias2bT = splat(bias2b); // C operands of the chains' first steps
     const f4 eT = {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f, i == 3 ? 1.f : 0.f}; // unit rows of the transposes
     JOut jo;
@@ -806,8 +820,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.start();
 #ifdef DP_PROFILE
     prof.t[10] = prof.prev - t_entry; // kernel entry -> first iteration
-    prof.t[12] = t_setup[0] - t_entry;    // first level, half of the stream, second level issued
-    prof.t[13] = t_setup[1] - t_setup[0]; // other half issued, frame blocks, trackers
+    prof.t[12] = t_setup[0] - t_entry;    // image fetched into LDS (barrier), flags decoded, tracker loads issued
+    prof.t[13] = t_setup[1] - t_setup[0]; // registers filled from LDS (barrier), frame blocks, trackers
     prof.t[14] = t_setup[2] - t_setup[1]; // LDS image, barrier
     prof.t[15] = prof.prev - t_setup[2];  // resident weights arrived
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;

@@ -41,7 +41,7 @@ if os.environ.get("DP_KERNEL") == "w4":
     print(f"  per launch: entry -> first iteration {raw[:, 10].mean() * N:.0f} cycles, last iteration -> stores done {raw[:, 11].mean() * N:.0f} cycles "
           f"(max over workgroups {raw[:, 10].max() * N:.0f} / {raw[:, 11].max() * N:.0f})")
     print(f"  shader clock held over the loop: {raw[:, 17].mean() / raw[:, 16].mean() * 0.1:.3f} GHz (s_memtime / s_memrealtime)")
-    print("  setup split (time of arrival, no drain): first level + half the stream + second level issued {:.0f}, other half issued + frame blocks + trackers {:.0f}, LDS image + barrier {:.0f}, resident weights arrived {:.0f}".format(
+    print("  setup split (time of arrival, no drain): image into LDS + flags + tracker loads issued {:.0f}, registers from LDS + frame blocks + trackers {:.0f}, barrier {:.0f}, loop entry {:.0f}".format(
         *[raw[:, i].mean() * N for i in (12, 13, 14, 15)]))
     print(f"  first iteration {raw[:, 18].mean() * N:.0f} cycles, second {raw[:, 19].mean() * N:.0f} (mean over all: {raw[:, 17].mean():.0f})")
 elif raw[:, 17:].any():  # ad-hoc sub-stamps (slots 17..19) of an experiment
