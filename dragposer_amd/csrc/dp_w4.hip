@@ -284,6 +284,17 @@ DEV Q4 quat_from_rotmat(const float* m)
 // tracker of rank `rank` of the frame whose tracked-joint mask is `tmask` (E of them), in two halves so that the setup can
 // have the inputs in flight while other loads are issued: tracker_fetch issues the global loads, tracker_finish rotates the
 // targets into the frame of `cur`, stores the record in the frame block (general path, epilogue) and returns it
+// position of the (rank + 1)-th set bit of m (31 if there is none): the largest p with popcount(m below p) <= rank
+DEV int nth_set_bit(unsigned m, int rank)
+{
+    int pos = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 1) {
+        const int c = __popc(m & ((1u << (pos + step)) - 1u));
+        pos += c <= rank ? step : 0;
+    }
+    return pos;
+}
 struct TRaw {
     bool act;
     int rank, j;
@@ -295,9 +306,7 @@ DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, in
     TRaw r;
     r.act = rank < E;
     r.rank = rank;
-    unsigned m = tmask;
-    for (int u = 0; u < rank; ++u) m &= m - 1u;
-    const int j = r.act ? __builtin_ctz(m | 0x80000000u) : 0;
+    const int j = r.act ? nth_set_bit(tmask, rank) : 0;
     r.j = j;
     r.plo = a.items[j].path_lo;
     r.phi = a.items[j].path_hi;
@@ -733,9 +742,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     __builtin_amdgcn_sched_barrier(0);
 
     // ... then the second level of the tracker chain (lane 4u+i: rank u of frame i), in flight under the rest
+    // bit j = (flag byte j != 0): per word, OR every byte down into its bit 0, then gather the four bits with one multiply
     unsigned tmask = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) tmask |= (((tflag[j >> 2] >> (8 * (j & 3))) & 0xffu) ? 1u : 0u) << j;
+    for (int k = 0; k < 6; ++k) {
+        unsigned v = tflag[k];
+        v |= v >> 4; v |= v >> 2; v |= v >> 1;
+        tmask |= ((((v & 0x01010101u) * 0x01020408u) >> 24) & (k < 5 ? 0xFu : 0x3u)) << (4 * k);
+    }
     if (!optimise) tmask = 0;
     const int E = min(__popc(tmask), W4_R);
     const int Emax = max(max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 1)),
