@@ -479,13 +479,13 @@ DEV void t_stage(const TRec& t, float* fb, bool losses)
     const f2 ownyz = k * s1; // torque on the tracked joint (and on the root)
     const V3 own = {ownx, ownyz.x, ownyz.y};
     const V3 ag = cross(at, gp);
-    // (fourth components are never read: anything already in a register serves -- a constant there makes the register
-    //  allocator clear a register of a tuple an LDS read is still writing, and wait for it)
     const f2 rtyz = f2{ag.y, ag.z} + ownyz;
     const V3 rt = {ag.x + own.x, rtyz.x, rtyz.y};
-    *(f4*)(fb + FB_GP + 4 * t.rank) = f4{gp.x, gp.y, gp.z, gp.z};
-    *(f4*)(fb + FB_RT + 4 * t.rank) = f4{rt.x, rt.y, rt.z, rt.z};
-    *(f4*)(fb + t.wt) = f4{own.x, own.y, own.z, own.z};
+    // (12-byte stores: the readers take 16 bytes and ignore the fourth word)
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    *(f3*)(fb + FB_GP + 4 * t.rank) = f3{gp.x, gp.y, gp.z};
+    *(f3*)(fb + FB_RT + 4 * t.rank) = f3{rt.x, rt.y, rt.z};
+    *(f3*)(fb + t.wt) = f3{own.x, own.y, own.z};
     if (losses) // (uniform) read by the epilogue
         *(f2*)(fb + FB_LP + 2 * t.rank) = f2{t.clp * (e.x * e.x + e.y * e.y + e.z * e.z), t.clr8 * (s.x * s.x + s.y * s.y + s.z * s.z)};
 }
@@ -519,7 +519,8 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
     f2 t0 = j.u[1] * S[2] - j.u[2] * S[1] + c.rho * S[0];
     f2 t1 = j.u[2] * S[0] - j.u[0] * S[2] + c.rho * S[1];
     f2 t2 = j.u[0] * S[1] - j.u[1] * S[0] + c.rho * S[2];
-    t0 += f2{wa.x, wb.x}; t1 += f2{wa.y, wb.y}; t2 += f2{wa.z, wb.z};
+    // (scalar adds on the halves: pairing wa / wb components for three packed adds costs four moves)
+    t0.x += wa.x; t0.y += wb.x; t1.x += wa.y; t1.y += wb.y; t2.x += wa.z; t2.y += wb.z;
     // dL/dq = (0, a) (x) q = (-a.v, w a + a x v), a = 2 tau   (root: q (x) (0, a): the cross product changes sign)
     const f2 a0 = t0 + t0, a1 = t1 + t1, a2 = t2 + t2;
     const f2 w = j.q[0], vx = j.q[1], vy = j.q[2], vz = j.q[3];
