@@ -415,7 +415,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     const bool pull = d->temporal && d->lambda_tmp != 0.f;
     dp_seq_state st = seq_state(d);
     if (pull) {
-        if (d->window < 0 || d->window % 4 != 0) { d->fail("drag_pose: temporalFutureWindow must be a non-negative multiple of 4 (sample_step)"); return; }
+        if (d->window < 0) { d->fail("drag_pose: temporalFutureWindow must not be negative"); return; } // (a multiple of the predictor's sample_step: dp_temporal_predict checks)
         if (d->target_window != d->window) { // (re)sized and zeroed, as drag_pose.py:238-246 does
             if (d->d_target) dp_io_free(d->ctx, d->d_target);
             d->d_target = nullptr;
