@@ -1,0 +1,50 @@
+"""CPU: the product's kernels as hipcc compiles them for gfx950 (the build flags of __graft_entry__): no register spills, no
+scratch, the register budget the design counts on.  A regression here costs performance silently -- the kernels still run."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+
+
+def _kernel_notes(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    flags = [f for f in G.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call(["hipcc", *flags, "-S", "--cuda-device-only", "-o", str(out), os.path.join(G.CSRC, src)],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    notes = {}
+    for blk in text.split("  - .agpr_count:")[1:]:  # one metadata block per kernel
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        get = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
+        notes[name] = dict(agpr=int(blk.split()[0]), vgpr=get("vgpr_count"), vspill=get("vgpr_spill_count"),
+                           scratch=get("private_segment_fixed_size"), lds=get("group_segment_fixed_size"))
+    return notes
+
+
+def test_optimise_kernel_keeps_its_register_budget(tmp_path):
+    notes = _kernel_notes("dp_w4.hip", tmp_path)
+    kernels = {k: v for k, v in notes.items() if "dp_w4_kernel" in k}
+    assert len(kernels) == 2, list(notes)  # <4, false> and <4, true> (early stop)
+    for name, n in kernels.items():
+        assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
+        assert n["agpr"] == 256, (name, n)          # every accumulator register holds a resident weight
+        assert n["lds"] <= 160 * 1024, (name, n)
+
+
+def test_temporal_kernel_variants_fit_their_occupancy(tmp_path):
+    notes = _kernel_notes("dp_temporal.hip", tmp_path)
+    kernels = {k: v for k, v in notes.items() if "dp_temporal_kernel" in k}
+    assert len(kernels) == 2, list(notes)
+    for name, n in kernels.items():
+        assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
+        assert n["lds"] <= 80 * 1024, (name, n)      # two workgroups per CU
+    assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, True]  # the 4-waves-per-SIMD variant and the 2-wave one
