@@ -38,6 +38,11 @@ def arrays_from_generator_model(generator_model, offsets):
     return arrs
 
 
+# what a frame step consumes of the kernel's results (the global rotation matrices `rot`, 198 floats per frame, are not among
+# them: the kernel skips them when the pointer is NULL)
+_RUN_OUTPUTS = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
+
+
 class DragPose:
     def __init__(self, generator_model, temporal_model, means_latent, stds_latent, device=None, device_gpu=None, n_sequences=1,
                  offsets=None, native_temporal=False):
@@ -210,11 +215,11 @@ class DragPose:
 
         self._flip ^= 1  # two result sets, alternated: `last` (and the latent it carries) stays valid while the next frame runs
         if self._out[self._flip] is None:
-            self._out[self._flip] = self.opt.allocate_outputs(S)
+            self._out[self._flip] = self.opt.allocate_outputs(S, _RUN_OUTPUTS)
         out = self.opt.optimize(self.latent, target_latent, self.current_global_rot, trk["tgt_pos"], trk["tgt_rot"], trk["w"],
                                 trk["tracked"], n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot),
                                 lambda_tmp=float(lambda_temporal), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
-                                min_loss_incr=min_loss_incr, max_trackers=E, out=self._out[self._flip])
+                                min_loss_incr=min_loss_incr, max_trackers=E, outputs=_RUN_OUTPUTS, out=self._out[self._flip])
         self.last = out
         self.latent = out["z"]
         if verbose:
