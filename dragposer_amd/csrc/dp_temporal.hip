@@ -3,7 +3,7 @@
 //
 // A torch.nn.Transformer (post-norm layers, ReLU, final encoder / decoder LayerNorm, no masks, dropout off) of width 48
 // over at most 32 tokens: far too small for one GPU to be busy with one sequence, so the unit of work is ONE WORKGROUP PER
-// SEQUENCE that runs the whole block -- token assembly from the history buffers, the encoder once, window / step + 1
+// SEQUENCE (or per two, when there are many: below) that runs the whole block -- token assembly from the history buffers, the encoder once, window / step + 1
 // autoregressive decoder calls (the reference passes no target mask, so every call recomputes all target positions),
 // de-normalisation and the step-hold "lerp" -- with every activation in LDS and the weights (5 MB fp32 at the reference's
 // size) streamed from L2.  All linear weights are stored TRANSPOSED ([in][out]) by dp_temporal_create, so that the lanes
@@ -52,10 +52,18 @@ struct TArgs {
 
 DEV f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// out[t][n] = b[col0 + n] + sum_k in[t][k] * wT[k][col0 + n] (+ pe[t][n])   (t < T, n < N, k < K <= 4 KS; wT has ldw columns)
+// Token layout.  The activations of a workgroup are rows of [MAXT][48] arrays, handled in tiles of 16 rows (the M or N
+// dimension of an MFMA).  NS = 1: one sequence, its T <= 32 tokens in rows 0 .. T-1 (the second tile only when T > 16).
+// NS = 2: two sequences, sequence s in tile s, T <= 16 tokens each -- every token-wise product then serves both with one
+// fetch of its weights.
+template <int NS> DEV int n_ttiles(int T) { return NS == 1 ? (T + 15) >> 4 : NS; }
+template <int NS> DEV int tile_tokens(int tt, int T) { return NS == 1 ? min(16, T - 16 * tt) : T; } // valid rows of tile tt
+template <int NS> DEV int pe_row(int tt, int tl) { return NS == 1 ? 16 * tt + tl : tl; }            // position of row tl of tile tt
+
+// out[t][n] = b[col0 + n] + sum_k in[t][k] * wT[k][col0 + n] (+ pe[pos(t)][n])   (n < N, k < K <= 4 KS; wT has ldw columns)
 // One 16 x 16 output tile per wave and turn: A[token][k] from LDS, B[k][n] one word per lane and K-step -- all KS loads
 // of a tile in flight together.
-template <int KS>
+template <int KS, int NS>
 DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* wT, int ldw, int col0, const float* b, int N, int K,
              const float* pe = nullptr)
 {
@@ -63,16 +71,16 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
     asm volatile("" : "+v"(lane)); // opaque per call: the per-lane weight addresses are recomputed (a few VALU operations) instead
                                    // of being hoisted out of the layer loops into registers the kernel does not have
     const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
-    const int ntiles = (N + 15) >> 4, jobs = ntiles * ((T + 15) >> 4);
+    const int ntiles = (N + 15) >> 4, jobs = ntiles * n_ttiles<NS>(T);
 #pragma unroll 1
     for (int job = wave; job < jobs; job += NWV) {
-        const int nt = job % ntiles, tt = job / ntiles, n = 16 * nt + l16, t = 16 * tt + l16;
+        const int nt = job % ntiles, tt = job / ntiles, n = 16 * nt + l16, tv = tile_tokens<NS>(tt, T);
         float bw[KS], av[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = 4 * ks + q;
             bw[ks] = (k < K && n < N) ? wT[(size_t)k * ldw + col0 + n] : 0.f;
-            av[ks] = (k < K && t < T) ? in[t * ldi + k] : 0.f;
+            av[ks] = (k < K && l16 < tv) ? in[(16 * tt + l16) * ldi + k] : 0.f;
         }
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -84,8 +92,45 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
             const float bias = b[col0 + n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int to = 16 * tt + 4 * q + r;
-                if (to < T) out[to * ldo + n] = acc0[r] + acc1[r] + bias + (pe ? pe[to * D + n] : 0.f);
+                const int tl = 4 * q + r;
+                if (tl < tv) out[(16 * tt + tl) * ldo + n] = acc0[r] + acc1[r] + bias + (pe ? pe[pe_row<NS>(tt, tl) * D + n] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the next target token of every sequence: out_proj of its LAST position (row T - 1 of its tile) -> 24 channels; the
+// sequences are the rows of one MFMA tile
+template <int NS>
+DEV void next_token(float* tok, float* preds, const float* x, int T, int it, bool feed, const float* wT, const float* b)
+{
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    if (wave < 2) { // two 16-column tiles of the 24 outputs
+        const int n = 16 * wave + l16;
+        float bw[D / 4], av[D / 4];
+#pragma unroll
+        for (int ks = 0; ks < D / 4; ++ks) {
+            const int k = 4 * ks + q;
+            bw[ks] = n < LAT ? wT[k * LAT + n] : 0.f;
+            av[ks] = l16 < NS ? x[((NS == 1 ? 0 : 16 * l16) + T - 1) * D + k] : 0.f;
+        }
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int ks = 0; ks < D / 4; ks += 2) {
+            acc0 = mfma(av[ks], bw[ks], acc0);
+            acc1 = mfma(av[ks + 1], bw[ks + 1], acc1);
+        }
+        if (n < LAT && q == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < NS) { // row r = sequence r
+                    const float v = acc0[r] + acc1[r] + b[n];
+                    preds[(r * (MAXT + 1) + it) * LAT + n] = v;
+                    if (feed) tok[((NS == 1 ? 0 : 16 * r) + T) * LAT + n] = v; // (read by the next call as target position T)
+                }
             }
         }
     }
@@ -121,13 +166,16 @@ DEV float wave_sum(float v)
 
 // x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm): one wave per token, one
 // lane per channel
+template <int NS>
 DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = lane < D;
     const float gc = live ? g[lane] : 0.f, bc = live ? b[lane] : 0.f;
+    const int rows = 16 * n_ttiles<NS>(T);
 #pragma unroll 1
-    for (int t = wave; t < T; t += NWV) {
+    for (int t = wave; t < rows; t += NWV) {
+        if ((t & 15) >= tile_tokens<NS>(t >> 4, T)) continue; // (uniform per wave)
         float v = 0.f;
         if (live) v = x[t * D + lane] + (o ? o[t * D + lane] : 0.f);
         const float mean = wave_sum(v) * (1.f / D);
@@ -140,24 +188,25 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 
 // q | k | v = in_proj(xq | xkv | xkv) in ONE phase: the nine 16-column tiles of the packed in_proj weight [48][144] (x token
 // tiles) are dealt to the waves; columns 0..47 take the query tokens, the rest the key / value tokens.
+template <int NS>
 DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* wT, const float* b)
 {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
     const int wave = threadIdx.x >> 6, l16 = lane & 15, qd = lane >> 4;
-    const int ttq = (Tq + 15) >> 4, ttk = (Tk + 15) >> 4, jobs = 3 * ttq + 6 * ttk;
+    const int ttq = n_ttiles<NS>(Tq), ttk = n_ttiles<NS>(Tk), jobs = 3 * ttq + 6 * ttk;
 #pragma unroll 1
     for (int job = wave; job < jobs; job += NWV) {
         const bool isq = job < 3 * ttq;
         const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : j2 / 6;
         const float* in = isq ? xq : xkv;
-        const int T = isq ? Tq : Tk, n = 16 * nt + l16, t = 16 * tt + l16;
+        const int tv = tile_tokens<NS>(tt, isq ? Tq : Tk), n = 16 * nt + l16;
         float bw[D / 4], av[D / 4];
 #pragma unroll
         for (int ks = 0; ks < D / 4; ++ks) {
             const int k = 4 * ks + qd;
             bw[ks] = wT[k * 3 * D + n];
-            av[ks] = t < T ? in[t * D + k] : 0.f;
+            av[ks] = l16 < tv ? in[(16 * tt + l16) * D + k] : 0.f;
         }
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -169,22 +218,25 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
         float* out = qkv + (n / D) * (MAXT * D) + (n % D); // q, k, v are consecutive [MAXT][D] arrays
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int to = 16 * tt + 4 * qd + r;
-            if (to < T) out[to * D] = acc0[r] + acc1[r] + bias;
+            const int tl = 4 * qd + r;
+            if (tl < tv) out[(16 * tt + tl) * D] = acc0[r] + acc1[r] + bias;
         }
     }
     __syncthreads();
 }
 
-// multi-head attention of Tq queries over Tk <= 32 keys (no mask), one wave per head, one phase:
+// multi-head attention of Tq queries over Tk <= 32 keys (no mask), one wave per (sequence, head), one phase:
 //   ao[i][h*HD + c] = sum_j softmax_j(q_i . k_j / sqrt(HD)) v[j][h*HD + c]
 // Lane (row r, j) -- r = lane / 16, j = lane % 16 -- holds keys j and j + 16; a turn of the loop takes four queries, one per
 // DPP row: 12-term dot products, the maximum and the sum over the keys by row reductions in registers, the probabilities
-// through this head's score rows in LDS (same wave: no barrier); then lane (query, channel) accumulates the output.
+// through the wave's score rows in LDS (same wave: no barrier); then lane (query, channel) accumulates the output.
+template <int NS>
 DEV void attention(float* ao, const float* q, const float* k, const float* v, float* sc, int Tq, int Tk)
 {
-    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-    if (h < NHD) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = wave & (NHD - 1), sq = wave / NHD; // NS = 1: waves 0..3, one per head; NS = 2: wave = 4 * sequence + head
+    if (sq < NS) {
+        q += 16 * sq * D; k += 16 * sq * D; v += 16 * sq * D; ao += 16 * sq * D; // (the sequence's tile)
         const float scale = 1.f / sqrtf((float)HD);
         const int j = lane & 15, r = lane >> 4;
         const bool live0 = j < Tk, live1 = j + 16 < Tk;
@@ -194,7 +246,7 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
             k0[c] = live0 ? k[j * D + h * HD + c] : 0.f;
             k1[c] = live1 ? k[(j + 16) * D + h * HD + c] : 0.f;
         }
-        float* sch = sc + h * MAXT * MAXT;
+        float* sch = sc + (NS == 1 ? h * MAXT * MAXT : wave * 16 * MAXT);
 #pragma unroll 1
         for (int i0 = 0; i0 < Tq; i0 += 4) {
             const int i = min(i0 + r, Tq - 1); // (a row beyond the last query recomputes it)
@@ -226,12 +278,13 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
 }
 
 // o = out_proj(attention(in_proj_q(xq), in_proj_k(xkv), in_proj_v(xkv)))
+template <int NS>
 DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const float* w, int in_wT, int in_b, int out_wT, int out_b,
              float* q, float* k, float* v, float* ao, float* sc)
 {
-    lin_qkv(q, xq, Tq, xkv, Tk, w + in_wT, w + in_b);
-    attention(ao, q, k, v, sc, Tq, Tk);
-    lin<D / 4>(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
+    lin_qkv<NS>(q, xq, Tq, xkv, Tk, w + in_wT, w + in_b);
+    attention<NS>(ao, q, k, v, sc, Tq, Tk);
+    lin<D / 4, NS>(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
 }
 
 // one tile of 16 hidden units: H^T = W1 X^T (12 MFMAs), bias + ReLU, OUT += H W2^T (12 MFMAs; the first product's
@@ -264,7 +317,8 @@ DEV void ffn_load(f4 (&im)[7], const f4* img, int nt, int ntiles)
 // o[t] = linear2(relu(linear1(x[t]))) + bias2  (header comment; pack layout in dp_temporal_create).
 // PREFETCH: a wave keeps the images of three tiles in flight (84 registers: the one-workgroup-per-CU kernel, where a SIMD
 // has two waves to hide an L2 round trip behind 768 cycles of MFMA per tile); otherwise one, and four waves per SIMD.
-template <bool PREFETCH>
+// NS = 2: every tile image serves the token tiles of both sequences.
+template <bool PREFETCH, int NS>
 DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red)
 {
     int lane = threadIdx.x & 63;
@@ -272,54 +326,75 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
     const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
     const int ntiles = (F + 15) >> 4;
     const f4* img = (const f4*)(w + pack) + lane;
+    constexpr int NG = NS == 1 ? 1 : NS; // token tiles that share one pass over the weights
 #pragma unroll 1
-    for (int tt = 0; tt < (T + 15) >> 4; ++tt) {
-        const int t = 16 * tt + l16;
-        float xb[D / 4]; // B operand of the first product: X^T[k][token]
+    for (int tt0 = 0; tt0 < n_ttiles<NS>(T); tt0 += NG) {
+        float xb[NG][D / 4]; // B operand of the first product: X^T[k][token]
+        f4 acc[NG][3];
 #pragma unroll
-        for (int ks = 0; ks < D / 4; ++ks) xb[ks] = t < T ? x[t * D + 4 * ks + q] : 0.f;
-        f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int g = 0; g < NG; ++g) {
+            const int tv = tile_tokens<NS>(tt0 + g, T);
+#pragma unroll
+            for (int ks = 0; ks < D / 4; ++ks) xb[g][ks] = l16 < tv ? x[(16 * (tt0 + g) + l16) * D + 4 * ks + q] : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
+        }
         if (PREFETCH) {
             f4 b0[7], b1[7], b2[7];
             int nt = wave;
             ffn_load(b0, img, nt, ntiles);
             ffn_load(b1, img, nt + NWV, ntiles);
             while (nt < ntiles) {
-                ffn_load(b2, img, nt + 2 * NWV, ntiles); ffn_tile(b0, xb, acc); nt += NWV;
+                ffn_load(b2, img, nt + 2 * NWV, ntiles);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) ffn_tile(b0, xb[g], acc[g]);
+                nt += NWV;
                 if (nt >= ntiles) break;
-                ffn_load(b0, img, nt + 2 * NWV, ntiles); ffn_tile(b1, xb, acc); nt += NWV;
+                ffn_load(b0, img, nt + 2 * NWV, ntiles);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) ffn_tile(b1, xb[g], acc[g]);
+                nt += NWV;
                 if (nt >= ntiles) break;
-                ffn_load(b1, img, nt + 2 * NWV, ntiles); ffn_tile(b2, xb, acc); nt += NWV;
+                ffn_load(b1, img, nt + 2 * NWV, ntiles);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) ffn_tile(b2, xb[g], acc[g]);
+                nt += NWV;
             }
         } else {
 #pragma unroll 1
             for (int nt = wave; nt < ntiles; nt += NWV) {
                 f4 cur[7];
                 ffn_load(cur, img, nt, ntiles);
-                ffn_tile(cur, xb, acc);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) ffn_tile(cur, xb[g], acc[g]);
             }
         }
-        // the waves' partial outputs: lane (channel l16 of tile ct, token group q), register r = token 4 q + r
+        // the waves' partial outputs, one token tile at a time through the reduction buffer: lane (channel l16 of tile ct,
+        // token group q), register r = token 4 q + r
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) *(f4*)(red + ((wave * 3 + ct) * 64 + lane) * 4) = acc[ct];
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 16 * D; idx += NT) {
-            const int tl = idx / D, c = idx - tl * D, to = 16 * tt + tl;
-            if (to < T) {
-                const int slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
-                float sum = w[l2b + c];
+        for (int g = 0; g < NG; ++g) {
+            const int tt = tt0 + g, tv = tile_tokens<NS>(tt, T);
 #pragma unroll
-                for (int wv = 0; wv < NWV; ++wv) sum += red[wv * 3 * 256 + slot];
-                o[to * D + c] = sum;
+            for (int ct = 0; ct < 3; ++ct) *(f4*)(red + ((wave * 3 + ct) * 64 + lane) * 4) = acc[g][ct];
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < 16 * D; idx += NT) {
+                const int tl = idx / D, c = idx - tl * D;
+                if (tl < tv) {
+                    const int slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
+                    float sum = w[l2b + c];
+#pragma unroll
+                    for (int wv = 0; wv < NWV; ++wv) sum += red[wv * 3 * 256 + slot];
+                    o[(16 * tt + tl) * D + c] = sum;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
 // OCC = waves per SIMD: 4 (two workgroups per CU, 128 registers: throughput with many sequences) or 2 (one workgroup per CU,
-// 256 registers, feed-forward weights prefetched three tiles deep: latency with few)
-template <int OCC>
+// 256 registers, feed-forward weights prefetched three tiles deep: latency with few).  NS = sequences per workgroup.
+template <int OCC, int NS>
 __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
 {
     __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D];
@@ -328,64 +403,70 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     __shared__ __attribute__((aligned(16))) float qkva[4 * MAXT * D];
     static_assert(4 * MAXT * D >= NWV * 3 * 64 * 4, "the reduction buffer fits the attention buffers");
     float *q = qkva, *kb = qkva + MAXT * D, *vb = qkva + 2 * MAXT * D, *ao = qkva + 3 * MAXT * D, *red = qkva;
-    __shared__ float sc[NHD * MAXT * MAXT], tok[(MAXT + 1) * LAT], enc_in[MAXT * MAX_IN], preds[(MAXT + 1) * LAT];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    if (s >= a.n_seq) return;
+    __shared__ float sc[NHD * MAXT * MAXT], tok[MAXT * LAT], enc_in[MAXT * MAX_IN], preds[NS * (MAXT + 1) * LAT];
+    const int s0 = blockIdx.x * NS, tid = threadIdx.x;
+    if (s0 >= a.n_seq) return;
     const float* w = a.w;
     const int H = a.H, step = a.step, n_past = (H + step - 1) / step, Te = n_past - 1, n_steps = a.window / step + 1;
 
-    // ---- tokens (drag_pose.py:249-266): latent normalised | displacement accumulated over `step` frames | heights
-    for (int idx = tid; idx < Te * a.n_in; idx += NT) {
-        const int t = idx / a.n_in, c = idx - t * a.n_in, fr = t * step;
-        float v;
-        if (c < LAT) v = (a.latent_buf[((size_t)s * H + fr) * LAT + c] - w[a.mean + c]) / w[a.stdv + c];
-        else if (c < LAT + 3) {
-            v = 0.f;
-            for (int j = 0; j < step && fr + j < H; ++j) v += a.disp_buf[((size_t)s * H + fr + j) * 3 + (c - LAT)];
-        } else v = a.heights_buf[((size_t)s * H + fr) * a.nh + (c - LAT - 3)];
-        enc_in[t * MAX_IN + c] = v;
+    // ---- tokens (drag_pose.py:249-266): latent normalised | displacement accumulated over `step` frames | heights.
+    //      Sequence slot sl of the workgroup fills rows 16 sl .. of the arrays (NS = 1: rows 0 .. Te-1); a slot beyond the
+    //      last sequence computes on zeros and stores nothing.
+    for (int idx = tid; idx < NS * Te * a.n_in; idx += NT) {
+        const int sl = idx / (Te * a.n_in), r2 = idx - sl * Te * a.n_in, t = r2 / a.n_in, c = r2 - t * a.n_in, fr = t * step;
+        const int s = s0 + sl;
+        float v = 0.f;
+        if (s < a.n_seq) {
+            if (c < LAT) v = (a.latent_buf[((size_t)s * H + fr) * LAT + c] - w[a.mean + c]) / w[a.stdv + c];
+            else if (c < LAT + 3) {
+                for (int j = 0; j < step && fr + j < H; ++j) v += a.disp_buf[((size_t)s * H + fr + j) * 3 + (c - LAT)];
+            } else v = a.heights_buf[((size_t)s * H + fr) * a.nh + (c - LAT - 3)];
+        }
+        enc_in[(16 * sl + t) * MAX_IN + c] = v;
     }
-    if (tid < LAT) tok[tid] = (a.latent_buf[((size_t)s * H + Te * step) * LAT + tid] - w[a.mean + tid]) / w[a.stdv + tid];
+    if (tid < NS * LAT) {
+        const int sl = tid / LAT, c = tid - sl * LAT, s = s0 + sl;
+        tok[16 * sl * LAT + c] = s < a.n_seq ? (a.latent_buf[((size_t)s * H + Te * step) * LAT + c] - w[a.mean + c]) / w[a.stdv + c] : 0.f;
+    }
     __syncthreads();
 
     // ---- encoder, once (the memory is the same for every autoregressive call)
-    lin<MAX_IN / 4>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
+    lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
     for (int l = 0; l < a.n_enc; ++l) {
         const TLayer L = ((const TLayer*)(w + a.enc_tab))[l];
-        mha(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
-        add_ln(x, o, Te, w + L.n1w, w + L.n1b);
-        ffn<OCC == 2>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
-        add_ln(x, o, Te, w + L.n2w, w + L.n2b);
+        mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
+        add_ln<NS>(x, o, Te, w + L.n1w, w + L.n1b);
+        ffn<OCC == 2, NS>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
+        add_ln<NS>(x, o, Te, w + L.n2w, w + L.n2b);
     }
-    add_ln(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
-    for (int idx = tid; idx < Te * D; idx += NT) mem[idx] = x[idx];
+    add_ln<NS>(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
+    for (int idx = tid; idx < MAXT * D; idx += NT) mem[idx] = x[idx];
     __syncthreads();
 
     // ---- autoregressive calls (drag_pose.py:274-279): call i sees i + 1 target tokens, keeps the last position's output
     for (int it = 0; it < n_steps; ++it) {
         const int T = it + 1;
-        lin<LAT / 4>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
+        lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
         for (int l = 0; l < a.n_dec; ++l) {
             const TLayer L = ((const TLayer*)(w + a.dec_tab))[l];
-            mha(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
-            add_ln(x, o, T, w + L.n1w, w + L.n1b);
-            mha(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
-            add_ln(x, o, T, w + L.n2w, w + L.n2b);
-            ffn<OCC == 2>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
-            add_ln(x, o, T, w + L.n3w, w + L.n3b);
+            mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
+            add_ln<NS>(x, o, T, w + L.n1w, w + L.n1b);
+            mha<NS>(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
+            add_ln<NS>(x, o, T, w + L.n2w, w + L.n2b);
+            ffn<OCC == 2, NS>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
+            add_ln<NS>(x, o, T, w + L.n3w, w + L.n3b);
         }
-        add_ln(x, nullptr, T, w + a.decn_w, w + a.decn_b);
-        lin<D / 4>(tok + T * LAT, LAT, x + (T - 1) * D, D, 1, w + a.op_wT, LAT, 0, w + a.op_b, LAT, D); // the next target token
-        if (tid < LAT) preds[it * LAT + tid] = tok[T * LAT + tid];
-        __syncthreads();
+        add_ln<NS>(x, nullptr, T, w + a.decn_w, w + a.decn_b);
+        next_token<NS>(tok, preds, x, T, it, it + 1 < n_steps, w + a.op_wT, w + a.op_b);
     }
 
     // ---- de-normalise, then the reference's "lerp" with weight 1 (drag_pose.py:283-291): frame k of the window holds the
     //      NEXT sampled prediction, the last frame its own
     const int W = a.window;
-    for (int idx = tid; idx < (W + 1) * LAT; idx += NT) {
-        const int k = idx / LAT, c = idx - k * LAT, m = k < W ? k / step + 1 : W / step;
-        a.target[((size_t)s * (W + 1) + k) * LAT + c] = preds[m * LAT + c] * w[a.stdv + c] + w[a.mean + c];
+    for (int idx = tid; idx < NS * (W + 1) * LAT; idx += NT) {
+        const int sl = idx / ((W + 1) * LAT), r2 = idx - sl * (W + 1) * LAT, k = r2 / LAT, c = r2 - k * LAT, m = k < W ? k / step + 1 : W / step;
+        if (s0 + sl < a.n_seq)
+            a.target[((size_t)(s0 + sl) * (W + 1) + k) * LAT + c] = preds[(sl * (MAXT + 1) + m) * LAT + c] * w[a.stdv + c] + w[a.mean + c];
     }
 }
 
@@ -395,7 +476,8 @@ thread_local std::string g_terr;
 
 struct dp_temporal {
     int device = -1, n_cu = 256;
-    int forced_occ = 0; // DP_TEMPORAL_OCC in the environment at dp_temporal_create: 2 or 4 = that kernel variant whatever the batch (tests)
+    int forced_variant = 0; // DP_TEMPORAL_VARIANT in the environment at dp_temporal_create: 21, 41 or 42 (waves per SIMD, sequences
+                            // per workgroup) = that kernel variant whatever the batch (tests)
     float* d_w = nullptr;
     TArgs args{};
     std::string err;
@@ -510,7 +592,7 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, DP_ERR_DEVICE, "dp_temporal_create: hipSetDevice failed");
     dp_temporal* t = new dp_temporal;
     t->device = device;
-    if (const char* e = std::getenv("DP_TEMPORAL_OCC")) t->forced_occ = std::atoi(e) == 2 ? 2 : (std::atoi(e) == 4 ? 4 : 0);
+    if (const char* e = std::getenv("DP_TEMPORAL_VARIANT")) t->forced_variant = std::atoi(e);
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->n_cu = cu; }
     hipError_t e = hipMalloc((void**)&t->d_w, buf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->d_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -555,9 +637,14 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     TArgs a = m;
     a.latent_buf = st->latent_buf; a.disp_buf = st->disp_buf; a.heights_buf = st->heights_buf;
     a.H = st->history; a.n_seq = n_seq; a.window = window; a.target = target_buf;
-    const bool few = t->forced_occ ? t->forced_occ == 2 : n_seq <= t->n_cu;
-    if (few) hipLaunchKernelGGL(dp_temporal_kernel<2>, dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(dp_temporal_kernel<4>, dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    // variant: few sequences -> latency (one workgroup per CU, prefetch); many -> two workgroups per CU, and two sequences per
+    // workgroup when each has at most 16 tokens (every weight fetch then serves both)
+    const bool pair_ok = n_past - 1 <= 16 && n_steps <= 16;
+    int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? 42 : 41);
+    if (t->forced_variant == 21 || t->forced_variant == 41 || (t->forced_variant == 42 && pair_ok)) variant = t->forced_variant;
+    if (variant == 21) hipLaunchKernelGGL((dp_temporal_kernel<2, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    else if (variant == 41) hipLaunchKernelGGL((dp_temporal_kernel<4, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dp_temporal_kernel<4, 2>), dim3((n_seq + 1) / 2), dim3(NT), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return tfail(t, DP_ERR_LAUNCH, std::string("dp_temporal_predict: ") + hipGetErrorString(e));

@@ -43,8 +43,8 @@ def test_optimise_kernel_keeps_its_register_budget(tmp_path):
 def test_temporal_kernel_variants_fit_their_occupancy(tmp_path):
     notes = _kernel_notes("dp_temporal.hip", tmp_path)
     kernels = {k: v for k, v in notes.items() if "dp_temporal_kernel" in k}
-    assert len(kernels) == 2, list(notes)
+    assert len(kernels) == 3, list(notes)  # <2, 1> (latency), <4, 1> and <4, 2> (two workgroups per CU; one / two sequences each)
     for name, n in kernels.items():
         assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
         assert n["lds"] <= 80 * 1024, (name, n)      # two workgroups per CU
-    assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, True]  # the 4-waves-per-SIMD variant and the 2-wave one
+    assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, True, True]  # the 2-waves-per-SIMD variant uses the full file

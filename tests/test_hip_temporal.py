@@ -35,12 +35,14 @@ def _torch_block(model, means, stds, lat, disp, hts, window):
     return buf
 
 
-@pytest.mark.parametrize("occ", [2, 4])  # the two kernel variants: one workgroup per CU with prefetch (few sequences) / two per CU
+# the kernel variants (waves per SIMD, sequences per workgroup): 21 = one workgroup per CU with prefetch (few sequences),
+# 41 = two workgroups per CU, 42 = two per CU with two sequences each (many sequences of at most 16 tokens)
+@pytest.mark.parametrize("variant", [21, 41, 42])
 @pytest.mark.parametrize("window", [0, 16, 60])
-def test_native_predictor_matches_nn_transformer_at_full_size(window, occ, monkeypatch):
+def test_native_predictor_matches_nn_transformer_at_full_size(window, variant, monkeypatch):
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
 
-    monkeypatch.setenv("DP_TEMPORAL_OCC", str(occ))  # read at dp_temporal_create
+    monkeypatch.setenv("DP_TEMPORAL_VARIANT", str(variant))  # read at dp_temporal_create
 
     torch.manual_seed(3)
     model = TemporalPredictor().eval()  # 3 + 3 layers, d_model 48, 4 heads, feed-forward 2048 (train_temporal.py:17-37)
@@ -56,18 +58,18 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window, occ, monke
     got = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
     assert got.shape == (S, window + 1, 24)
     err = (got - want).abs().max().item()
-    print(f"window {window}, variant {occ}: max |native - nn.Transformer| = {err:.2e} (targets of magnitude {want.abs().max().item():.2f})")
+    print(f"window {window}, variant {variant}: max |native - nn.Transformer| = {err:.2e} (targets of magnitude {want.abs().max().item():.2f})")
     # fp32 against fp32 in a different summation order through 6 LayerNorm-ed layers and up to 16 autoregressive calls
     assert err <= 1e-5, err
 
 
-@pytest.mark.parametrize("occ", [2, 4])
+@pytest.mark.parametrize("occ", [21, 41, 42])  # (42 is not applicable beyond 16 tokens: the library falls back to 41)
 def test_more_than_sixteen_tokens_take_two_tiles(occ, monkeypatch):
     """window 100 = 26 autoregressive calls, the last ones over 17..26 target tokens: two 16-token tiles in every product,
     keys beyond 16 in the attention; a feed-forward width that is not a multiple of 16 (zero-padded tile)."""
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
 
-    monkeypatch.setenv("DP_TEMPORAL_OCC", str(occ))
+    monkeypatch.setenv("DP_TEMPORAL_VARIANT", str(occ))
     torch.manual_seed(5)
     model = TemporalPredictor(n_encoder_layers=2, n_decoder_layers=2, dim_feedforward=200).eval()
     for p in model.parameters():
