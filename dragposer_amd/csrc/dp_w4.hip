@@ -260,23 +260,19 @@ DEV V3 rot_conj(Q4 q, V3 a)
 }
 
 DEV Q4 quat_from_rotmat(const float* m)
-{ // row-major 3x3 rotation -> unit quaternion (Shepperd's branches; once per tracker, before the loop)
+{ // row-major 3x3 rotation -> unit quaternion (once per tracker, before the loop).  Shepperd's four branches pick the
+  // largest of (w, x, y, z) to divide by; since the result is normalised anyway, each branch is just four sums scaled by a
+  // common factor -- the candidates are built without a division or a square root and ONE is selected (the branch
+  // conditions of the textbook form), then normalised.
     const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
     const float tr = m00 + m11 + m22;
+    const float a = m21 - m12, b = m02 - m20, c = m10 - m01, d = m01 + m10, e = m02 + m20, f = m12 + m21;
+    const bool s0 = tr > 0.f, s1 = m00 > m11 && m00 > m22, s2 = m11 > m22;
     Q4 q;
-    if (tr > 0.f) {
-        const float s = sqrtf(tr + 1.f) * 2.f;
-        q = {0.25f * s, (m21 - m12) / s, (m02 - m20) / s, (m10 - m01) / s};
-    } else if (m00 > m11 && m00 > m22) {
-        const float s = sqrtf(1.f + m00 - m11 - m22) * 2.f;
-        q = {(m21 - m12) / s, 0.25f * s, (m01 + m10) / s, (m02 + m20) / s};
-    } else if (m11 > m22) {
-        const float s = sqrtf(1.f + m11 - m00 - m22) * 2.f;
-        q = {(m02 - m20) / s, (m01 + m10) / s, 0.25f * s, (m12 + m21) / s};
-    } else {
-        const float s = sqrtf(1.f + m22 - m00 - m11) * 2.f;
-        q = {(m10 - m01) / s, (m02 + m20) / s, (m12 + m21) / s, 0.25f * s};
-    }
+    q.w = s0 ? 1.f + tr : (s1 ? a : (s2 ? b : c));
+    q.x = s0 ? a : (s1 ? 1.f + m00 - m11 - m22 : (s2 ? d : e));
+    q.y = s0 ? b : (s1 ? d : (s2 ? 1.f + m11 - m00 - m22 : f));
+    q.z = s0 ? c : (s1 ? e : (s2 ? f : 1.f + m22 - m00 - m11));
     const float n = 1.f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     return {q.w * n, q.x * n, q.y * n, q.z * n};
 }
