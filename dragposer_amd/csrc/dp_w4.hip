@@ -769,10 +769,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     // ---- under the stream: frame blocks, trackers, LDS image
     // what has to read as zero in a frame block: the own-torque slots of untracked joints, the two tracker tables (stage G
     // reads rows beyond a frame's tracker count) and the bones' zero slot
-    constexpr int NZ = 32 + 2 * W4_R + 1;
+    // (... and the tracker loss terms, which the stop test sums over all ranks: FB_LP follows FB_WT)
+    constexpr int NW_LP = 32 + W4_R / 2, NZ = NW_LP + 2 * W4_R + 1;
+    static_assert(FB_LP == FB_WT + 128 && W4_R % 2 == 0, "the loss terms follow the own-torque slots");
     for (int k = lane; k < FPW * NZ; k += 64) {
         const int fr = k / NZ, r = k % NZ;
-        *(f4*)(fb0 + fr * FB_STRIDE + (r < 32 ? FB_WT + 4 * r : r < 32 + 2 * W4_R ? FB_GP + 4 * (r - 32) : FB_BN + 4 * SLOT_ZERO)) = f4{0.f, 0.f, 0.f, 0.f};
+        *(f4*)(fb0 + fr * FB_STRIDE + (r < NW_LP ? FB_WT + 4 * r : r < NW_LP + 2 * W4_R ? FB_GP + 4 * (r - NW_LP) : FB_BN + 4 * SLOT_ZERO)) = f4{0.f, 0.f, 0.f, 0.f};
     }
     static_assert(MAX_ITERS <= NW * 64, "one row of the Adam table per thread");
     if (tid < a.n_iter) *(f2*)(lds + L_TAB + 2 * tid) = adam_row;
@@ -900,25 +902,38 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         unsigned actmask = 0xFu, stopmask = 0u; // bit r: frame f0 + r runs this iteration / stops after its step
         if (EARLY) {
             bool was_act = false, stop_now = false;
-            if (b == 0) { // lane i: the stop test of frame i
+            { // the stop test of frame i, in EVERY lane of the frame's column (no branch: the reads and sums interleave with stage
+              // G's; the state -- es_prev, es_act, es_iters -- is replicated over the column)
+                // the loss terms of ALL ranks (zero beyond the frame's count: the set-up cleared them), read together -- a loop
+                // over the frame's own count waits one LDS round trip per tracker -- and added in rank order
                 float lp = 0.f, lr = 0.f, lt = 0.f;
-                for (int e0 = 0; e0 < E; ++e0) { const f2 l = *(const f2*)(fb + FB_LP + 2 * e0); lp += l.x; lr += l.y; }
+                if (Emax <= 8) { // (uniform)
+                    f4 l[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) l[k] = *(const f4*)(fb + FB_LP + 4 * k);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { lp += l[k].x; lr += l[k].y; lp += l[k].z; lr += l[k].w; }
+                } else {
+                    f4 l[W4_R / 2];
+#pragma unroll
+                    for (int k = 0; k < W4_R / 2; ++k) l[k] = *(const f4*)(fb + FB_LP + 4 * k);
+#pragma unroll
+                    for (int k = 0; k < W4_R / 2; ++k) { lp += l[k].x; lr += l[k].y; lp += l[k].z; lr += l[k].w; }
+                }
 #pragma unroll
                 for (int k = 0; k < LAT; k += 4) { const f4 d = *(const f4*)(fb + FB_LT + k); lt += (d.x + d.y) + (d.z + d.w); }
                 lt *= a.lam_tmp * (1.f / 24.f);
                 const float tot = (lp + lr) + lt;
                 const bool cont = (lp > a.stop_eps_pos || lr > a.stop_eps_rot) && (es_prev - tot > a.min_loss_incr) && !last;
                 was_act = es_act;
-                if (es_act) {
-                    es_prev = tot;
-                    ++es_iters;
-                    *(f4*)(fb + FB_ES) = f4{lp, lr, lt, 0.f};
-                }
+                es_prev = es_act ? tot : es_prev;
+                es_iters += es_act ? 1 : 0;
+                if (es_act && b == 0) *(f4*)(fb + FB_ES) = f4{lp, lr, lt, 0.f};
                 stop_now = es_act && !cont;
                 es_act = es_act && cont;
             }
-            actmask = (unsigned)__ballot(was_act) & 0xFu;
-            stopmask = (unsigned)__ballot(stop_now) & 0xFu;
+            actmask = (unsigned)__ballot(was_act && b == 0) & 0xFu;
+            stopmask = (unsigned)__ballot(stop_now && b == 0) & 0xFu;
         }
         f4 gyA, gyB;
         g_stage(pc, fb, jo, tmask, Emax, gyA, gyB);
@@ -980,8 +995,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #pragma unroll
             for (int r = 0; r < FPW; ++r) {
                 if ((actmask >> r) & 1u) { // (uniform)
-                    if (lane < LAT) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r]; // latent of this frame's (so far) last forward pass
                     if ((stopmask >> r) & 1u) {
+                        if (lane < LAT) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r]; // latent of this frame's LAST forward pass
                         zfinD[r] = zN[r]; // the frame's loop ends with this step; z, m, v stay as they are
                     } else {
                         zD[r] = zN[r]; mD[r] = mN[r]; vD[r] = vN[r];
