@@ -103,17 +103,18 @@ PUBLIC_SYMBOLS = (
     "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict",
 )
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the shared library (once).  Raises RuntimeError with the build hint when absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load the shared library (once per path; the product never passes one -- tests do, for the test-only second
+    implementation libdragposer_hip_ref8.so).  Raises RuntimeError with the build hint when absent."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  dragposer_amd has no CPU fallback."
         )
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the device pointers / streams
@@ -124,7 +125,7 @@ def load():
     bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
     if os.path.exists(bundled):
         C.CDLL(bundled, mode=C.RTLD_GLOBAL)
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.dp_version.restype = C.c_int
     lib.dp_last_error.restype = C.c_char_p
     lib.dp_last_error.argtypes = [C.c_void_p]
@@ -145,7 +146,7 @@ def load():
                                       C.c_void_p, C.c_void_p]
     lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f, C.POINTER(C.c_uint)]
     lib.dp_debug_items.argtypes = [C.POINTER(DpModel), C.c_void_p]
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

@@ -29,9 +29,17 @@ struct dp_ctx {
     std::vector<unsigned> smask;
     std::string err;
     float mean_q0[4] = {0, 0, 0, 0}, std_q0[4] = {1, 1, 1, 1}; // root quaternion channels (sequence epilogue)
-    int forced_kernel = 0; // DP_KERNEL in the environment at dp_create: 8 = the 8-wave kernel of dp_kernel.hip (comparisons)
-    int last_kernel = 0;   // 4 (wave-private, dp_w4.hip) or 8: what the last launch used
+    int last_kernel = 0;   // what the last launch used: 4 = dp_w4.hip (8 in the test-only library, below)
 };
+
+// The product library has ONE optimise kernel (dp_w4.hip).  Round 1's 8-wave kernel (dp_kernel.hip: the reference's matrix
+// chain taken literally, 16x16x4 tiles) survives as an independent second implementation for cross-checks in a TEST-ONLY
+// library, libdragposer_hip_ref8.so = this file compiled with -DDP_REF8_BUILD + dp_kernel.o; no environment variable is read.
+#ifdef DP_REF8_BUILD
+constexpr int KERNEL_CHOICE = 8;
+#else
+constexpr int KERNEL_CHOICE = 4;
+#endif
 
 static thread_local std::string g_create_err;
 
@@ -416,7 +424,6 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     dp_ctx* ctx = new dp_ctx();
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = std::getenv("DP_KERNEL")) ctx->forced_kernel = !std::strcmp(e, "8") ? 8 : 0; // read once, here
     for (int k = 0; k < 4; ++k) { ctx->mean_q0[k] = model->mean_q[k]; ctx->std_q0[k] = model->std_q[k]; }
     int rc = dp_fold_decoder(model, &ctx->folded);
     std::vector<float> wfrag(NWAVE * W_REGS * 64), bfrag(128);
@@ -512,10 +519,16 @@ extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
 
 extern "C" int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int* threads_per_block, int* lds_bytes)
 { // of the kernel the context's launches use
-    const int k = ctx && (ctx->last_kernel == 8 || (ctx->last_kernel == 0 && ctx->forced_kernel == 8)) ? 8 : 4;
-    if (frames_per_block) *frames_per_block = k == 4 ? dp_w4_frames_per_block() : FPB;
-    if (threads_per_block) *threads_per_block = k == 4 ? 256 : NTHREADS;
-    if (lds_bytes) *lds_bytes = k == 4 ? dp_w4_lds_bytes() : dp_kernel_lds_bytes();
+    (void)ctx;
+#ifdef DP_REF8_BUILD
+    if (frames_per_block) *frames_per_block = FPB;
+    if (threads_per_block) *threads_per_block = NTHREADS;
+    if (lds_bytes) *lds_bytes = dp_kernel_lds_bytes();
+#else
+    if (frames_per_block) *frames_per_block = dp_w4_frames_per_block();
+    if (threads_per_block) *threads_per_block = 256;
+    if (lds_bytes) *lds_bytes = dp_w4_lds_bytes();
+#endif
     return DP_OK;
 }
 
@@ -539,14 +552,17 @@ static void fill_results(const dp_result* out, KArgs& k)
 }
 
 // Which kernel runs a launch: the wave-private kernel of dp_w4.hip (4 frames per wave, no workgroup barrier in the
-// loop).  DP_KERNEL=8 in the environment AT dp_create selects the previous decomposition (dp_kernel.hip: 16 frames per
-// 8-wave workgroup) for comparisons; both implement the same operator within the tolerance of tests/test_hip_w4.py.
+// loop); in the test-only library the previous decomposition (dp_kernel.hip: 16 frames per 8-wave workgroup).  Both
+// implement the same operator within the tolerance of tests/test_hip_w4.py.
 static int launch(dp_ctx* ctx, KArgs& k, void* stream)
 {
     DEVICE_GUARD(ctx);
-    const int choice = ctx->forced_kernel == 8 ? 8 : 4;
-    ctx->last_kernel = choice;
-    hipError_t e = choice == 8 ? dp_launch_optimize(&k, (hipStream_t)stream) : dp_launch_w4(&k, (hipStream_t)stream);
+    ctx->last_kernel = KERNEL_CHOICE;
+#ifdef DP_REF8_BUILD
+    hipError_t e = dp_launch_optimize(&k, (hipStream_t)stream);
+#else
+    hipError_t e = dp_launch_w4(&k, (hipStream_t)stream);
+#endif
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
     return DP_OK;
 }

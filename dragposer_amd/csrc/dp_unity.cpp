@@ -312,6 +312,10 @@ void load_models(DragPoser* d, char* modelPath)
         d->target_window = -1;
         dp_destroy(d->ctx);
         d->ctx = nullptr;
+        // the device state (latent / displacement / height histories, global pose) is gone with the buffers: the caller
+        // has to call init_drag_model again before the next drag_pose, and the temporal window restarts
+        d->initialised = false;
+        d->current_index = 0;
     }
     if (dp_create(&d->ctx, &m, 0) != DP_OK) { d->fail(std::string("dp_create: ") + dp_last_error(nullptr)); return; }
     if (dp_io_alloc(d->ctx, IN_FLOATS * sizeof(float), &d->d_in) != DP_OK || dp_io_alloc(d->ctx, OUT_FLOATS * sizeof(float), &d->d_out) != DP_OK ||
@@ -412,11 +416,18 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     b.z0 = di + IN_Z0; b.z_tgt = di + IN_ZT; b.cur_rot = di + IN_ROT; b.tgt_pos = di + IN_TP; b.tgt_rot = di + IN_TR; b.w = di + IN_W;
     b.tracked = (const unsigned char*)(di + IN_TRK);
     // temporal target block (drag_pose.py:234-294): a prediction every `window` frames, one row of it per frame
-    const bool pull = d->temporal && d->lambda_tmp != 0.f;
+    // The reference runs its predictor at current_index == 0 whatever lambda_temporal is (drag_pose.py:235-291), so the
+    // target buffer always holds the current window's prediction when the pull is switched on mid-window; so does this.
+    const bool have_predictor = d->temporal != nullptr;
+    const bool pull = have_predictor && d->lambda_tmp != 0.f;
     dp_seq_state st = seq_state(d);
-    if (pull) {
+    if (have_predictor) {
         if (d->window < 0) { d->fail("drag_pose: temporalFutureWindow must not be negative"); return; } // (a multiple of the predictor's sample_step: dp_temporal_predict checks)
         if (d->target_window != d->window) { // (re)sized and zeroed, as drag_pose.py:238-246 does
+            // Unity's SetLambdas may change the window mid-window.  The reference keeps current_index and then indexes the
+            // re-allocated (window + 1)-row buffer with it: an IndexError when the window shrank, rows of zeros until the
+            // next prediction when it grew.  Here a changed window restarts the window: a prediction is made this frame.
+            d->current_index = 0;
             if (d->d_target) dp_io_free(d->ctx, d->d_target);
             d->d_target = nullptr;
             const std::vector<float> zeros((size_t)(d->window + 1) * LAT, 0.f);
@@ -429,7 +440,8 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
             d->fail(std::string("drag_pose: ") + dp_temporal_last_error(d->temporal));
             return;
         }
-        b.z_tgt = (float*)d->d_target + (size_t)d->current_index * LAT;
+        if (d->current_index > d->window) { d->fail("drag_pose: temporal window index out of range"); return; } // (cannot happen: see above)
+        if (pull) b.z_tgt = (float*)d->d_target + (size_t)d->current_index * LAT;
     }
     dp_params p;
     p.n_iter = d->max_iter; p.lr = d->lr; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f;

@@ -43,8 +43,8 @@ def _check(t, name, shape, dtype, device):
 class LatentOptimizer:
     """One context per device.  Not thread-safe (same contract as the C ABI)."""
 
-    def __init__(self, model_path=DEFAULT_MODEL, device="cuda:0", weight_dtype="fp32", arrays=None):
-        self.lib = _lib.load()
+    def __init__(self, model_path=DEFAULT_MODEL, device="cuda:0", weight_dtype="fp32", arrays=None, _lib_path=None):
+        self.lib = _lib.load(_lib_path)  # (_lib_path: tests only -- the second implementation kept for cross-checks)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("LatentOptimizer needs a ROCm device (cuda:N); there is no CPU fallback")
@@ -55,7 +55,8 @@ class LatentOptimizer:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         rc = self.lib.dp_create(C.byref(self.ctx), C.byref(self.host_model.struct), idx)
         if rc != _lib.DP_OK:
-            raise _lib.DragPoserError(rc, _lib.last_error())
+            msg = self.lib.dp_last_error(None)
+            raise _lib.DragPoserError(rc, msg.decode() if msg else "")
         fpb, tpb, lds = C.c_int(), C.c_int(), C.c_int()
         self.lib.dp_kernel_geometry(self.ctx, C.byref(fpb), C.byref(tpb), C.byref(lds))
         self.frames_per_block, self.threads_per_block, self.lds_bytes = fpb.value, tpb.value, lds.value
@@ -78,7 +79,8 @@ class LatentOptimizer:
             pass
 
     def _fail(self, rc):
-        raise _lib.DragPoserError(rc, _lib.last_error(self.ctx))
+        msg = self.lib.dp_last_error(self.ctx)
+        raise _lib.DragPoserError(rc, msg.decode() if msg else "")
 
     def allocate_outputs(self, B, names=None):
         """a reusable set of result tensors for `optimize(..., out=...)`"""
@@ -96,15 +98,20 @@ class LatentOptimizer:
 
     def optimize(self, z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter=50, lr=1e-2, betas=(0.9, 0.999),
                  eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=None,
-                 max_trackers=0, outputs=None, out=None, _debug=None):
+                 max_trackers=0, outputs=None, out=None, validate_targets=False, _debug=None):
         """All inputs are device tensors: z0/z_tgt [B,24], cur_rot [B,4], tgt_pos [B,22,3],
         tgt_rot [B,22,9], w [B,22,2] (fp32) and tracked [B,22] (uint8).  Returns a dict of device
         tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream.
         With stop_eps_* > 0 or min_loss_incr given, every frame runs the reference's own while-condition
         (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter).
-        `max_trackers`: ignored (a kernel-selection hint of version 1; kept so that old callers keep working)."""
+        `max_trackers`: ignored (a kernel-selection hint of version 1; kept so that old callers keep working).
+        `validate_targets`: check that every tracked joint's tgt_rot is a rotation matrix (the kernel evaluates the
+        reference's |R - T|^2 in its quaternion form, equal only for orthonormal det +1 targets: include/dragposer.h) --
+        costs a device reduction and a host synchronisation, so it is off by default."""
         B = int(z0.shape[0])
         dev = self.device
+        if validate_targets:
+            check_rotation_targets(tgt_rot, tracked)
         batch = _lib.DpBatch()
         batch.n_frames = B
         batch.z0 = _check(z0, "z0", (B, LATENT), torch.float32, dev)
@@ -179,6 +186,20 @@ class LatentOptimizer:
         rc = self.lib.dp_sequence_advance(self.ctx, S, C.byref(res), C.byref(st), C.byref(step), stream)
         if rc != _lib.DP_OK:
             self._fail(rc)
+
+
+def check_rotation_targets(tgt_rot, tracked, tol=1e-3):
+    """Raises ValueError unless every tracked joint's 3x3 target is orthonormal with determinant +1 (within `tol`)."""
+    R = tgt_rot.reshape(-1, NJ, 3, 3)
+    m = tracked.reshape(-1, NJ).bool()
+    if not bool(m.any()):
+        return
+    Rt = R[m].double()
+    dev_orth = (Rt @ Rt.transpose(-1, -2) - torch.eye(3, dtype=Rt.dtype, device=Rt.device)).abs().amax()
+    dev_det = (torch.linalg.det(Rt) - 1.0).abs().amax()
+    worst = float(torch.maximum(dev_orth, dev_det))
+    if not worst <= tol:
+        raise ValueError(f"tgt_rot: tracked targets must be rotation matrices (orthonormal, det +1); worst deviation {worst:.3g} > {tol}")
 
 
 def to_device_batch(np_batch, device):

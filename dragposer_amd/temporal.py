@@ -116,9 +116,11 @@ class NativeTemporal:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("NativeTemporal runs on an MI355X only (there is no CPU fallback)")
+        if self.device.index is None:  # "cuda" = the current device, as LatentOptimizer resolves it
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_heights = m.n_heights
         h = C.c_void_p()
-        rc = self._lib.dp_temporal_create(C.byref(h), C.byref(m), self.device.index or 0)
+        rc = self._lib.dp_temporal_create(C.byref(h), C.byref(m), self.device.index)
         if rc != _lib.DP_OK:
             msg = self._lib.dp_temporal_last_error(None)
             raise _lib.DragPoserError(rc, msg.decode() if msg else "")

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DP_VERSION 100 /* 0.1.0 */
+#define DP_VERSION 300 /* 0.3.0: round 3 -- max_trackers ignored since 0.2, dp_temporal_* added in 0.2, dp_optimize_sequence in 0.3 */
 
 #define DP_NUM_JOINTS 22
 #define DP_LATENT 24
@@ -101,7 +101,9 @@ typedef struct dp_batch {
                              (orthonormal, det +1) -- what the reference's callers pass (eval_drag.py:186-199 from FK,
                              run_drag.py:136 from quaternions): the kernel turns each into a quaternion once per launch and
                              evaluates |R - T|_F^2 as 8 |vec(conj(q_R) q_T)|^2, which equals the reference's element-wise
-                             form only for rotations */
+                             form only for rotations.  NOT validated here (device memory, no hidden sync): the Python
+                             operator checks it on request (LatentOptimizer.optimize(validate_targets=True): one device
+                             reduction and one host sync, raises ValueError beyond 1e-3) */
     const float* w;       /* [B][22][2] */
     const unsigned char* tracked; /* [B][22] */
 } dp_batch;

@@ -10,8 +10,10 @@
  * Differences, all deliberate and reported through drag_poser_last_error():
  *   - load_models(modelPath) reads <modelPath>/dragposer_model.bin (flat export of generator.pt + data.pt,
  *     written by tools/export_model_bin.py) instead of un-pickling generator.pt / temporal.pt;
- *   - the temporal Transformer is not part of this library: the pull term is switched off
- *     (lambda_temporal treated as 0) -- the reference's temporal.pt is not distributed with it either;
+ *   - the temporal Transformer runs natively (dp_temporal_* of include/dragposer.h) when <modelPath>/temporal.bin is
+ *     present (tools/export_temporal_bin.py writes it from a temporal.pt state_dict); without that file -- the
+ *     reference's temporal.pt is not distributed with it -- a non-zero lambdaTemporal is accepted, the pull term stays
+ *     off and drag_poser_last_error() says so;
  *   - functions that can fail keep the reference's void signatures; the message of the last failure is
  *     available from drag_poser_last_error(handle) (an addition, the reference only logs to a file).
  * Conventions are the reference's: quaternions (w,x,y,z); caller-owned buffers; result_pose holds

@@ -1,5 +1,5 @@
 """GPU (MI355X): the wave-private kernel (dp_w4.hip, what every launch uses) against the previous decomposition
-(dp_kernel.hip, 16 frames per 8-wave workgroup, selected with DP_KERNEL=8 at context creation).
+(dp_kernel.hip, 16 frames per 8-wave workgroup: the test-only library libdragposer_hip_ref8.so).
 
 The two kernels are independent implementations of the same operator -- other tiling (v_mfma_f32_4x4x1 vs 16x16x4),
 other summation orders, another (torque-form) statement of the kinematics gradient -- so their agreement is a check
@@ -34,7 +34,6 @@ def dev():
 def opt(dev):
     from dragposer_amd.optimizer import LatentOptimizer
 
-    os.environ.pop("DP_KERNEL", None)
     o = LatentOptimizer(device=dev)
     assert o.kernel_geometry()[:2] == (16, 256)
     return o
@@ -44,11 +43,10 @@ def opt(dev):
 def opt8(dev):
     from dragposer_amd.optimizer import LatentOptimizer
 
-    os.environ["DP_KERNEL"] = "8"  # read once, at dp_create
-    try:
-        o = LatentOptimizer(device=dev)
-    finally:
-        os.environ.pop("DP_KERNEL", None)
+    from dragposer_amd import _lib
+
+    ref8 = os.path.join(os.path.dirname(_lib.LIB_PATH), "libdragposer_hip_ref8.so")  # test-only library (__graft_entry__.build)
+    o = LatentOptimizer(device=dev, _lib_path=ref8)
     assert o.kernel_geometry()[:2] == (16, 512)
     return o
 

@@ -128,10 +128,17 @@ def _recording_fk(rot, global_pos, offsets, parents):
 ref_drag_pose.fk_rotmat = _recording_fk
 
 
-def build_reference(parents, weight_rounding=None):
+def build_reference(parents, weight_rounding=None, dtype=torch.float32):
+    """dtype = torch.float64: the SAME reference code with every module, buffer and constant in double precision
+    (torch's default dtype is switched before anything is constructed; the checkpoint's fp32 values are copied into
+    double parameters by load_state_dict, the dataset statistics are cast)."""
+    torch.set_default_dtype(dtype)
     td = Train_Data("cpu", ref_train.param, None)
     gm = Generator_Model("cpu", ref_train.param, list(int(p) for p in parents), td)
     ref_train.load_model(gm, os.path.join(REF, "models/model_dancedb/generator.pt"), td, "cpu")
+    td.set_means(td.mean_dqs.to(dtype), td.mean_displacement.to(dtype))
+    td.set_stds(td.std_dqs.to(dtype), td.std_displacement.to(dtype))
+    assert next(gm.autoencoder.decoder.parameters()).dtype == dtype
     if weight_rounding == "bf16":
         # S4: every decoder *weight* tensor rounded to bf16 (biases, masks, unpool untouched)
         with torch.no_grad():
@@ -261,6 +268,107 @@ def run_recipe(name, B, track, cfg_weights, lam_tmp, n_iter, offsets_t, parents,
                 min_loss_incr=1e-5 if early_stop else None, torch=torch.__version__)
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     return out
+
+
+def run_frames(inp, n_iter, lam_tmp, offsets, parents, dtype=torch.float32, weight_rounding=None, progress=None):
+    """The REAL DragPose.run on given inputs (dense per-joint arrays of SURVEY 8a: z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w,
+    tracked), fixed iteration count, in precision `dtype`; returns what the parity tests compare (fp32 arrays)."""
+    gm, td, drag, stub = build_reference(parents, weight_rounding, dtype)
+    offsets_t = torch.tensor(offsets, dtype=dtype)
+    B = len(inp["z0"])
+    out = dict(pos=np.zeros((B, NJ, 3), np.float32), z_final=np.zeros((B, 24), np.float32), z_pre=np.zeros((B, 24), np.float32),
+               loss_last=np.zeros((B, 3), np.float64))
+    for b in range(B):
+        tr = np.nonzero(inp["tracked"][b])[0]
+        idx = torch.tensor(tr, dtype=torch.int64)
+        tp = torch.tensor(inp["tgt_pos"][b][tr], dtype=dtype)
+        tR = torch.tensor(inp["tgt_rot"][b][tr].reshape(-1, 3, 3), dtype=dtype)
+        wj = torch.tensor(inp["w"][b][tr], dtype=dtype)
+        reset_state(drag, torch.tensor(inp["z0"][b], dtype=dtype), torch.tensor(inp["cur_rot"][b], dtype=dtype))
+        stub.z_tgt = torch.tensor(inp["z_tgt"][b], dtype=dtype)
+        drag.run(target_ee_pos=tp, target_ee_rot=tR, mask_joints=idx, weights_joints=wj, offsets=offsets_t,
+                 stop_eps_pos=0.0, stop_eps_rot=0.0, max_iter=n_iter, min_loss_incr=-float("inf"), learning_rate=1e-2,
+                 lambda_rot=1, lambda_temporal=lam_tmp, temporal_future_window=0, height_indices=[0, 4, 8, 13, 17, 21],
+                 joint_adjustment_indices=None, joint_adjustment_weight=0.0, verbose=False)
+        assert len(drag.rec) == n_iter
+        last = drag.rec[-1]
+        out["pos"][b] = last["pos"].numpy()
+        out["z_final"][b] = drag.latent.detach().reshape(24).numpy()
+        out["z_pre"][b] = drag.current_latent.reshape(24).numpy()
+        out["loss_last"][b] = last["losses"]
+        if progress and b % 64 == 0:
+            print(f"[{progress}] frame {b}/{B}", flush=True)
+    return out
+
+
+def _run_frames_worker(job):
+    torch.set_num_threads(1)
+    return run_frames(*job[0], **job[1])
+
+
+def run_frames_parallel(inp, n_iter, lam_tmp, offsets, parents, workers, **kw):
+    """run_frames over `workers` forked processes (frames are independent; each worker builds its own reference objects)"""
+    import multiprocessing as mp
+
+    B = len(inp["z0"])
+    cuts = np.linspace(0, B, workers + 1).astype(int)
+    jobs = []
+    for k in range(workers):
+        sl = slice(cuts[k], cuts[k + 1])
+        kwk = dict(kw)
+        kwk["progress"] = (kw.get("progress") or "run") + f" w{k}" if k == 0 else None
+        jobs.append((({key: v[sl] for key, v in inp.items()}, n_iter, lam_tmp, offsets, parents), kwk))
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_run_frames_worker, jobs)
+    return {key: np.concatenate([p[key] for p in parts], 0) for key in parts[0]}
+
+
+def inputs_digest(inp):
+    import hashlib
+
+    h = hashlib.sha256()
+    for key in ("z0", "z_tgt", "cur_rot", "tgt_pos", "tgt_rot", "w", "tracked"):
+        h.update(np.ascontiguousarray(inp[key]).tobytes())
+    return h.hexdigest()
+
+
+def add_f64(name, gold, offsets, parents, workers):
+    """Re-run a committed fixture's stored inputs through the real reference in float64 and add pos_f64 / z_final_f64 /
+    z_pre_f64 / loss_last_f64 to it (the fp32 arrays already in the file are left as they are) -- the parity tests define a
+    "sensitive" frame as one where the REFERENCE's fp32 and fp64 runs part ways, not through the repo's own oracles."""
+    path = os.path.join(gold, f"{name}.npz")
+    raw = dict(np.load(path))
+    meta = json.loads(bytes(raw["meta"]).decode())
+    inp = {k: raw[k] for k in ("z0", "z_tgt", "cur_rot", "tgt_pos", "tgt_rot", "w", "tracked")}
+    o = run_frames_parallel(inp, meta["n_iter"], meta["lambda_tmp"], offsets, parents, workers, dtype=torch.float64,
+                            weight_rounding=None if meta["weight_rounding"] == "none" else meta["weight_rounding"], progress=name + "_f64")
+    for k in ("pos", "z_final", "z_pre", "loss_last"):
+        raw[k + "_f64"] = o[k]
+    np.savez_compressed(path, **raw)
+    d = np.linalg.norm(raw["pos"] - raw["pos_f64"], axis=-1).max(1) * 1000
+    print(f"{name}: reference fp32 vs fp64: max {d.max():.4f} mm, frames above 0.02 mm: {np.nonzero(d > 0.02)[0].tolist()} "
+          f"({np.round(d[d > 0.02], 3).tolist()})")
+
+
+def full_size_reference(name, B, seed, gold, offsets, parents, workers):
+    """BASELINE's headline batch (recipe S1, B frames, 50 iterations, inputs exactly as tests/bench.py draw them through
+    oracle.ref_torch.synth_inputs) through the REAL reference in fp32 and in fp64.  The fixture holds no inputs (the tests
+    re-draw them and check the digest), the fp32 reference positions / latents of every frame, per frame the distance between
+    the reference's own fp32 and fp64 runs, and the fp64 positions of the frames where that distance exceeds 0.02 mm."""
+    sys.path.insert(0, REPO)
+    from oracle import ref_torch as R  # inputs only: the recipe the GPU tests and bench.py use
+
+    inp = R.synth_inputs(R.OracleModel(), B, seed=seed)
+    o32 = run_frames_parallel(inp, 50, 0.02, offsets, parents, workers, dtype=torch.float32, progress=name + "_f32")
+    o64 = run_frames_parallel(inp, 50, 0.02, offsets, parents, workers, dtype=torch.float64, progress=name + "_f64")
+    d = (np.linalg.norm(o32["pos"] - o64["pos"], axis=-1).max(1) * 1000).astype(np.float32)
+    sens = np.nonzero(d > 0.02)[0].astype(np.int32)
+    meta = dict(name=name, B=B, seed=seed, n_iter=50, lambda_tmp=0.02, digest=inputs_digest(inp), torch=torch.__version__)
+    path = os.path.join(gold, f"{name}.npz")
+    np.savez_compressed(path, pos=o32["pos"], z_final=o32["z_final"], z_pre=o32["z_pre"], loss_last=o32["loss_last"].astype(np.float32),
+                        ref32_vs_ref64_mm=d, sens_frames=sens, pos_f64_sens=o64["pos"][sens], z_final_f64_sens=o64["z_final"][sens],
+                        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print(f"wrote {path} {os.path.getsize(path)} bytes; reference fp32 vs fp64 > 0.02 mm on frames {sens.tolist()} ({np.round(d[sens], 3).tolist()} mm)")
 
 
 def export_model(parents, offsets):
@@ -430,6 +538,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3,sequ,enc")
     ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--workers", type=int, default=6)
     args = ap.parse_args()
     todo = args.only.split(",")
     parents, offsets = parse_bvh_skeleton(os.path.join(REF, "data/example/eval/example.bvh"))
@@ -460,6 +569,12 @@ def main():
             path = os.path.join(gold, f"{name}.npz")
             np.savez_compressed(path, **out)
             print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+    for name in ("s1", "s3", "s4"):
+        if name + "_f64" in todo:  # adds the reference's own float64 run to a committed fixture
+            add_f64(name, gold, offsets, parents, args.workers)
+    for name, Bf in (("full1024", 1024), ("full4096", 4096)):  # BASELINE config 2 / the headline batch, whole, through the reference
+        if name in todo:
+            full_size_reference(name, Bf, 1234, gold, offsets, parents, args.workers)
     if "enc" in todo:
         path = os.path.join(gold, "enc.npz")
         np.savez_compressed(path, **encoder_golden(parents))
