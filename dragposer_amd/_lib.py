@@ -17,6 +17,7 @@ DP_ERR_LAUNCH = -4
 DP_WEIGHTS_FP32 = 0
 DP_WEIGHTS_BF16 = 1
 DP_MAX_ITERS = 256
+DP_KERNEL_AUTO, DP_KERNEL_W4, DP_KERNEL_W16 = 0, 1, 2
 
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int)
@@ -53,6 +54,7 @@ class DpParams(C.Structure):
         ("n_iter", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("lambda_rot", C.c_float), ("lambda_tmp", C.c_float), ("early_stop", C.c_int),
         ("stop_eps_pos", C.c_float), ("stop_eps_rot", C.c_float), ("min_loss_incr", C.c_float), ("max_trackers", C.c_int),
+        ("kernel", C.c_int),
     ]
 
 
@@ -146,6 +148,7 @@ def load(path=None):
                                       C.c_void_p, C.c_void_p]
     lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f, C.POINTER(C.c_uint)]
     lib.dp_debug_items.argtypes = [C.POINTER(DpModel), C.c_void_p]
+    lib.dp_debug_pack_w16.argtypes = [C.POINTER(DpFolded), C.POINTER(DpModel), C.c_void_p, C.c_void_p, C.c_void_p]
     _libs[path] = lib
     return lib
 

@@ -24,6 +24,10 @@ struct dp_ctx {
     float* d_w4img = nullptr;
     float* d_w4bias = nullptr;
     dpw4::Pair* d_w4pairs = nullptr;
+    unsigned* d_w16img = nullptr; // 16-frames-per-wave kernel (dp_w16.hip); NULL when the skeleton is not the one its slot map is for
+    float* d_w16bias = nullptr;
+    dpw16::SlotConst* d_w16slots = nullptr;
+    int weight_dtype = DP_WEIGHTS_FP32;
     ItemConst* d_items = nullptr;
     dp_folded folded;
     std::vector<unsigned> smask;
@@ -435,6 +439,12 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     if (rc == DP_OK) rc = dp_debug_items(model, items.data());
     std::vector<dpw4::Pair> pairs(16);
     if (rc == DP_OK) rc = dp_debug_pairs_w4(model, pairs.data());
+    const bool w16 = rc == DP_OK && dp_w16_supported(model);
+    std::vector<unsigned> w16img(w16 ? dpw16::IMG_U32 : 0);
+    std::vector<float> w16bias(dpw16::BIAS_FLOATS);
+    std::vector<dpw16::SlotConst> w16slots(dpw16::NTY * 4);
+    if (w16) rc = dp_debug_pack_w16(&ctx->folded, model, w16img.data(), w16bias.data(), w16slots.data());
+    ctx->weight_dtype = model->weight_dtype;
     if (rc != DP_OK) { delete ctx; return rc; }
     int prev = 0;
     hipGetDevice(&prev);
@@ -446,6 +456,14 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4bias, w4bias.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w4pairs, pairs.size() * sizeof(dpw4::Pair));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w4pairs, pairs.data(), pairs.size() * sizeof(dpw4::Pair), hipMemcpyHostToDevice);
+    if (w16) {
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w16img, w16img.size() * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w16bias, w16bias.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_w16slots, w16slots.size() * sizeof(dpw16::SlotConst));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_w16img, w16img.data(), w16img.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_w16bias, w16bias.data(), w16bias.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_w16slots, w16slots.data(), w16slots.size() * sizeof(dpw16::SlotConst), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w4img, w4img.data(), w4img.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w4bias, w4bias.data(), w4bias.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_wfrag, wfrag.data(), wfrag.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -455,6 +473,7 @@ extern "C" int dp_create(dp_ctx** out, const dp_model* model, int device)
     if (e != hipSuccess) {
         std::string msg = std::string("dp_create: ") + hipGetErrorString(e);
         hipFree(ctx->d_wfrag); hipFree(ctx->d_bias); hipFree(ctx->d_items); hipFree(ctx->d_w4img); hipFree(ctx->d_w4bias); hipFree(ctx->d_w4pairs);
+        hipFree(ctx->d_w16img); hipFree(ctx->d_w16bias); hipFree(ctx->d_w16slots);
         delete ctx;
         return fail(nullptr, DP_ERR_DEVICE, msg);
     }
@@ -472,6 +491,9 @@ extern "C" int dp_destroy(dp_ctx* ctx)
     hipFree(ctx->d_w4img);
     hipFree(ctx->d_w4bias);
     hipFree(ctx->d_w4pairs);
+    hipFree(ctx->d_w16img);
+    hipFree(ctx->d_w16bias);
+    hipFree(ctx->d_w16slots);
     delete ctx;
     return DP_OK;
 }
@@ -525,9 +547,10 @@ extern "C" int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int*
     if (threads_per_block) *threads_per_block = NTHREADS;
     if (lds_bytes) *lds_bytes = dp_kernel_lds_bytes();
 #else
-    if (frames_per_block) *frames_per_block = dp_w4_frames_per_block();
+    const bool k16 = ctx && ctx->last_kernel == 16;
+    if (frames_per_block) *frames_per_block = k16 ? dp_w16_frames_per_block() : dp_w4_frames_per_block();
     if (threads_per_block) *threads_per_block = 256;
-    if (lds_bytes) *lds_bytes = dp_w4_lds_bytes();
+    if (lds_bytes) *lds_bytes = k16 ? dp_w16_lds_bytes() : dp_w4_lds_bytes();
 #endif
     return DP_OK;
 }
@@ -541,6 +564,9 @@ static void fill_model_args(const dp_ctx* ctx, KArgs& k)
     k.w4img = ctx->d_w4img;
     k.w4bias = ctx->d_w4bias;
     k.w4pairs = ctx->d_w4pairs;
+    k.w16img = ctx->d_w16img;
+    k.w16bias = ctx->d_w16bias;
+    k.w16slots = ctx->d_w16slots;
     std::memcpy(k.smask, ctx->smask.data(), sizeof(k.smask));
 }
 
@@ -554,14 +580,16 @@ static void fill_results(const dp_result* out, KArgs& k)
 // Which kernel runs a launch: the wave-private kernel of dp_w4.hip (4 frames per wave, no workgroup barrier in the
 // loop); in the test-only library the previous decomposition (dp_kernel.hip: 16 frames per 8-wave workgroup).  Both
 // implement the same operator within the tolerance of tests/test_hip_w4.py.
-static int launch(dp_ctx* ctx, KArgs& k, void* stream)
+static int launch(dp_ctx* ctx, KArgs& k, void* stream, int kernel = DP_KERNEL_W4)
 {
     DEVICE_GUARD(ctx);
     ctx->last_kernel = KERNEL_CHOICE;
 #ifdef DP_REF8_BUILD
+    (void)kernel;
     hipError_t e = dp_launch_optimize(&k, (hipStream_t)stream);
 #else
-    hipError_t e = dp_launch_w4(&k, (hipStream_t)stream);
+    if (kernel == DP_KERNEL_W16) ctx->last_kernel = 16;
+    hipError_t e = kernel == DP_KERNEL_W16 ? dp_launch_w16(&k, (hipStream_t)stream) : dp_launch_w4(&k, (hipStream_t)stream);
 #endif
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
     return DP_OK;
@@ -599,7 +627,15 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
         k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
     }
-    return launch(ctx, k, stream);
+    // which kernel (include/dragposer.h: DP_KERNEL_*)
+    const bool w16_can = ctx->d_w16img != nullptr && !k.early_stop;
+    if (p->kernel != DP_KERNEL_AUTO && p->kernel != DP_KERNEL_W4 && p->kernel != DP_KERNEL_W16)
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize: unknown kernel selector");
+    if (p->kernel == DP_KERNEL_W16 && !w16_can)
+        return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 runs a fixed iteration count on the reference's 22-joint skeleton only");
+    const int kernel = p->kernel == DP_KERNEL_W16 || (p->kernel == DP_KERNEL_AUTO && w16_can && ctx->weight_dtype == DP_WEIGHTS_BF16 && in->n_frames >= 8192)
+                           ? DP_KERNEL_W16 : DP_KERNEL_W4;
+    return launch(ctx, k, stream, kernel);
 }
 
 extern "C" int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, void* stream)

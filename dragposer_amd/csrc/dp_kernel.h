@@ -1,8 +1,10 @@
 // dp_kernel.h -- argument block shared by the host side (dp_host.cpp) and the kernel (dp_kernel.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/dragposer.h"
 #include "dp_layout.h"
 #include "dp_w4.h"
+#include "dp_w16.h"
 
 struct AdamTab { // per-iteration scalars torch's single-tensor Adam computes in Python doubles
     float step[dpl::MAX_ITERS]; // lr / (1 - beta1^t)
@@ -23,6 +25,9 @@ struct KArgs {
     const float* w4img;          // [dpw4::N_GROUPS][64][4]  weight image of the wave-private kernel (dp_w4.h)
     const float* w4bias;         // [4][64] accumulator seeds of L0, L1, L2A, L2B
     const dpw4::Pair* w4pairs;   // [16] kinematics constants per lane quad
+    const unsigned* w16img;      // [dpw16::IMG_U32] split-precision weight image of the 16-frames-per-wave kernel (dp_w16.h)
+    const float* w16bias;        // [dpw16::BIAS_FLOATS]
+    const dpw16::SlotConst* w16slots; // [6 tiles][4 groups]
     // batch (device)
     const float *z0, *z_tgt, *cur_rot, *tgt_pos, *tgt_rot, *w;
     const unsigned char* tracked;
@@ -45,3 +50,9 @@ extern "C" int dp_kernel_lds_bytes(void);
 extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream);
 extern "C" int dp_w4_lds_bytes(void);
 extern "C" int dp_w4_frames_per_block(void);
+// dp_w16.hip: 16 frames per wave, decoder on v_mfma_f32_16x16x32_bf16 in split precision (fixed iteration count only)
+extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream);
+extern "C" int dp_w16_lds_bytes(void);
+extern "C" int dp_w16_frames_per_block(void);
+extern "C" int dp_w16_supported(const dp_model* m);
+extern "C" int dp_debug_pack_w16(const dp_folded* f, const dp_model* m, unsigned* img, float* bias, void* slots_out);

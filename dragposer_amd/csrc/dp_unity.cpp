@@ -448,6 +448,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     p.lambda_rot = d->lambda_rot; p.lambda_tmp = pull ? d->lambda_tmp : 0.f;
     p.early_stop = 1; p.stop_eps_pos = d->stop_eps_pos; p.stop_eps_rot = d->stop_eps_rot; p.min_loss_incr = 0.00001f; // run() default
     p.max_trackers = 0;
+    p.kernel = DP_KERNEL_AUTO;
     dp_result r;
     std::memset(&r, 0, sizeof(r));
     r.z = dout + OUT_Z; r.z_pre = dout + OUT_ZPRE; r.pose = dout + OUT_POSE; r.disp = dout + OUT_DISP; r.world_disp = dout + OUT_WD;

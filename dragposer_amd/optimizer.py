@@ -98,13 +98,15 @@ class LatentOptimizer:
 
     def optimize(self, z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter=50, lr=1e-2, betas=(0.9, 0.999),
                  eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=None,
-                 max_trackers=0, outputs=None, out=None, validate_targets=False, _debug=None):
+                 max_trackers=0, outputs=None, out=None, validate_targets=False, kernel="auto", _debug=None):
         """All inputs are device tensors: z0/z_tgt [B,24], cur_rot [B,4], tgt_pos [B,22,3],
         tgt_rot [B,22,9], w [B,22,2] (fp32) and tracked [B,22] (uint8).  Returns a dict of device
         tensors (see include/dragposer.h: dp_result).  Asynchronous on torch's current stream.
         With stop_eps_* > 0 or min_loss_incr given, every frame runs the reference's own while-condition
         (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter).
         `max_trackers`: ignored (a kernel-selection hint of version 1; kept so that old callers keep working).
+        `kernel`: "auto" | "w4" (4 frames per wave, fp32 MFMA) | "w16" (16 frames per wave, decoder on bf16 MFMA in split
+        precision; fixed iteration count only) -- include/dragposer.h: DP_KERNEL_*.
         `validate_targets`: check that every tracked joint's tgt_rot is a rotation matrix (the kernel evaluates the
         reference's |R - T|^2 in its quaternion form, equal only for orthonormal det +1 targets: include/dragposer.h) --
         costs a device reduction and a host synchronisation, so it is off by default."""
@@ -125,7 +127,8 @@ class LatentOptimizer:
         p = _lib.DpParams(n_iter=int(n_iter), lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, lambda_rot=lambda_rot,
                           lambda_tmp=lambda_tmp, early_stop=int(early), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
                           min_loss_incr=float("-inf") if min_loss_incr is None else min_loss_incr,
-                          max_trackers=int(max_trackers))
+                          max_trackers=int(max_trackers),
+                          kernel={"auto": _lib.DP_KERNEL_AUTO, "w4": _lib.DP_KERNEL_W4, "w16": _lib.DP_KERNEL_W16}[kernel])
         names = tuple(outputs) if outputs is not None else tuple(_OUT_SPECS)
         res, tensors = self._outputs(B, names, out)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -117,7 +117,18 @@ typedef struct dp_params {
     float stop_eps_pos, stop_eps_rot, min_loss_incr;
     int max_trackers;  /* ignored (kept for ABI compatibility with version 1, where it selected a kernel variant): every
                           joint of a frame may carry a tracker, whatever this says */
+    int kernel;        /* DP_KERNEL_AUTO / _W4 / _W16 (below); callers written against 0.2 must zero it */
 } dp_params;
+
+/* Two kernels implement dp_optimize (same operator, same outputs, within the tolerance stated in DESIGN.md):
+ *   DP_KERNEL_W4   4 frames per wavefront, fp32 MFMA (v_mfma_f32_4x4x1): every launch shape, early stop, forward-only.
+ *   DP_KERNEL_W16  16 frames per wavefront, decoder on v_mfma_f32_16x16x32_bf16 in split precision (every fp32 operand the
+ *                  exact sum of three bf16 terms, six term products per block accumulated in fp32): fixed iteration count
+ *                  only, the reference's 22-joint skeleton only; DP_ERR_UNSUPPORTED otherwise.  Pays from ~8192 frames.
+ *   DP_KERNEL_AUTO W16 for bf16-weight contexts (DP_WEIGHTS_BF16) with at least 8192 frames and no early stop, W4 otherwise. */
+#define DP_KERNEL_AUTO 0
+#define DP_KERNEL_W4 1
+#define DP_KERNEL_W16 2
 
 /* Outputs, DEVICE pointers; any may be NULL.  All but z are those of the LAST forward pass
  * (the latent before the final Adam step), as the reference returns them (drag_pose.py:309-312). */

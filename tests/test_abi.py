@@ -31,7 +31,7 @@ def test_struct_layouts_match_header_sizes():
     ptr = C.sizeof(C.c_void_p)
     assert C.sizeof(_lib.DpModel) == 20 * ptr + 8  # 20 pointers + int (+pad)
     assert C.sizeof(_lib.DpBatch) == 8 + 7 * ptr
-    assert C.sizeof(_lib.DpParams) == 12 * 4
+    assert C.sizeof(_lib.DpParams) == 13 * 4
     assert C.sizeof(_lib.DpResult) == 10 * ptr
     assert C.sizeof(_lib.DpSeqState) == 5 * ptr + 10 * 4  # 5 pointers, history, n_heights, height_joints[8]
     assert C.sizeof(_lib.DpSeqStep) == 16 + 3 * ptr      # 2 ints + float (+pad), 3 pointers

@@ -7,11 +7,13 @@ but its gradient is not: the decoder's two LeakyReLU layers switch slope (1 <-> 
 pre-activation crosses zero.  On a frame whose trajectory takes some pre-activation within fp32
 rounding of zero (|pre| of a few 1e-6 or less; typical minimum over 50 iterations: 3e-4), two correct
 implementations pick different slopes for that unit, their gradients differ by O(1) on its path, and
-the optimisation continues down another route.  Those frames are a property of the data, not of an
-implementation: they are identified in-test as the frames on which the CPU oracle disagrees WITH
-ITSELF between fp32 and fp64 arithmetic (1 of the 64 frames of the 3-tracker fixture, 2 of 4096
-synthetic 6-tracker frames), and `_kink_distance` checks the mechanism on them.  On them the bound
-is a few mm plus agreement of the final loss; everywhere else it is the strict 0.05 mm.
+the optimisation continues down another route.  WHICH frames do so depends on the last bit of every
+implementation's arithmetic; THAT some do is a property of the data: the reference's own fp32 and fp64 runs
+(same code, same inputs; stored in the fixtures by tools/make_goldens.py) part ways on 1 of the 64 frames of the
+3-tracker fixture (2.1 mm) and on 1 of the 4096 frames of the headline batch (3.2 mm).  Frames the reference
+flags that way, and frames on which `_kink_distance` shows the mechanism, are bounded at a few mm plus agreement
+of the final loss; everything else is held to the strict 0.05 mm.  Where no reference run exists (inputs made up
+in a test) the repo's fp32 / fp64 C oracles play the reference pair's role (`_sensitive_frames`).
 """
 import os
 
@@ -37,6 +39,21 @@ def _sensitive_frames(b, n_iter, lam, weight_rounding="none"):
     o32 = AnalyticOracle(precision="f32", weight_rounding=weight_rounding).optimize(*a, n_iter, lam_tmp=lam)
     o64 = AnalyticOracle(precision="f64", weight_rounding=weight_rounding).optimize(*a, n_iter, lam_tmp=lam)
     return _mm(o32["pos"], o64["pos"]).max(axis=1) > 0.02, o32
+
+
+def _ref_sensitive(g):
+    """Frames on which the REFERENCE's own fp32 and fp64 runs (same code, same inputs; tools/make_goldens.py --only NAME_f64)
+    part ways by more than 0.02 mm at some joint: sensitivity as a property of the data, stated without the repo's oracles."""
+    return _mm(g["pos"], g["pos_f64"]).max(axis=1) > 0.02
+
+
+def _inputs_digest(b):
+    import hashlib
+
+    h = hashlib.sha256()
+    for k in KEYS:
+        h.update(np.ascontiguousarray(b[k]).tobytes())
+    return h.hexdigest()
 
 
 def _kink_distance(b, frames, n_iter, lam):
@@ -137,7 +154,10 @@ def test_golden_parity_6_trackers(opt, opt_bf16, golden_dir, name):
     mt = g["meta"]
     o = _run(opt_bf16 if mt["weight_rounding"] == "bf16" else opt, g, mt["n_iter"], mt["lambda_tmp"])
     err = _mm(o["pos"], g["pos"])
-    assert err.max() <= 0.05, err.max()
+    assert not _ref_sensitive(g).any()  # (the reference's fp32 and fp64 runs agree on every frame of these fixtures)
+    print(f"{name}: vs the reference's fp32 run max {err.max():.5f} mm, vs its fp64 run {_mm(o['pos'], g['pos_f64']).max():.5f} mm; "
+          f"the reference's own pair {_mm(g['pos'], g['pos_f64']).max():.5f} mm")
+    assert err.max() <= (0.5 if mt["weight_rounding"] == "bf16" else 0.05), err.max()  # S4 = 10 x S1
     np.testing.assert_allclose(o["z"], g["z_final"], atol=5e-5)
     np.testing.assert_allclose(o["z_pre"], g["z_pre"], atol=5e-5)
     np.testing.assert_allclose(o["world_rot"], g["world_rot"], atol=5e-6)
@@ -149,19 +169,25 @@ def test_golden_parity_6_trackers(opt, opt_bf16, golden_dir, name):
 
 
 def test_golden_parity_3_trackers_100_iters(opt, golden_dir):
+    """BASELINE config 4 / SURVEY 8d recipe S3 (3 trackers, 100 iterations, under-constrained legs) against the reference's own
+    run, in BASELINE's terms: over all B x 22 joint positions mean <= 0.05 mm and p99 <= 1 mm; max <= 3 mm -- except on frames
+    the REFERENCE itself cannot reproduce between fp32 and fp64 (frame 14 of this fixture: 2.14 mm between its two runs), where
+    an implementation-independent answer does not exist and the bound is 10 mm plus an optimum of the same quality."""
     g = R.load_golden(os.path.join(golden_dir, "s3.npz"))
     mt = g["meta"]
     o = _run(opt, g, mt["n_iter"], mt["lambda_tmp"])
-    err = _mm(o["pos"], g["pos"]).max(axis=1)
-    sens, _ = _sensitive_frames(g, mt["n_iter"], mt["lambda_tmp"])
-    kink = _kink_distance(g, np.nonzero(sens)[0], mt["n_iter"], mt["lambda_tmp"])
-    print(f"s3: flagged by the oracle pair {np.nonzero(sens)[0].tolist()} (errors {np.round(err[sens], 3).tolist()} mm, smallest "
-          f"|pre-activation| {kink.tolist()}); largest error elsewhere {err[~sens].max():.4f} mm")
-    # frame 14 of this fixture: every CPU implementation diverges on it (1.4 - 6.2 mm).  Not a LeakyReLU kink here (its
-    # smallest |pre-activation| is 6e-5): with three trackers the legs are unconstrained, the optimum is a flat valley and
-    # 100 Adam steps amplify rounding along it -- the under-constrained path BASELINE config 4 names.
+    e = _mm(o["pos"], g["pos"])  # [B, 22]
+    err = e.max(axis=1)
+    sens = _ref_sensitive(g)
+    e64 = _mm(o["pos"], g["pos_f64"]).max(axis=1)
+    ref_pair = _mm(g["pos"], g["pos_f64"])
+    print(f"s3 vs the reference's fp32 run: mean {e.mean():.4f} mm, p99 {np.percentile(e, 99):.4f} mm, max {e.max():.4f} mm (BASELINE: 0.05 / 1 / 3); "
+          f"the reference's own fp32 vs fp64: mean {ref_pair.mean():.4f}, p99 {np.percentile(ref_pair, 99):.4f}, max {ref_pair.max():.4f}; "
+          f"reference-flagged frames {np.nonzero(sens)[0].tolist()}: GPU vs ref fp32 {np.round(err[sens], 3).tolist()} mm, vs ref fp64 "
+          f"{np.round(e64[sens], 3).tolist()} mm; largest error elsewhere {err[~sens].max():.4f} mm")
     assert 0 < sens.sum() <= 3
-    assert err[~sens].max() <= 0.05, err[~sens].max()
+    assert e.mean() <= 0.05 and np.percentile(e, 99) <= 1.0, (e.mean(), np.percentile(e, 99))
+    assert err[~sens].max() <= 0.05, err[~sens].max()  # (BASELINE allows 3 mm here; observed 0.011)
     assert err[sens].max() <= 10.0, err[sens].max()
     np.testing.assert_allclose(o["z"][~sens], g["z_final"][~sens], atol=5e-4)
     tot_ref, tot = g["loss_hist"][:, -1].sum(1), o["loss"].sum(1)
@@ -196,13 +222,16 @@ def test_ragged_batches_equal_full_batch_rows(opt, golden_dir, B):
         np.testing.assert_array_equal(sub[k], full[k][:B])  # a frame's result never depends on its batch
 
 
-def test_full_size_batch_properties(opt, dev):
-    """BASELINE config (4096 frames x 50 iters): determinism, batch-position invariance, parity
-    against the C oracle on every frame, and the optimiser actually optimises."""
+def test_full_size_batch_properties(opt, dev, golden_dir):
+    """BASELINE's headline batch (4096 frames x 50 iterations): determinism, batch-position invariance, and parity on EVERY
+    frame against the REAL reference's fp32 run of the same inputs (tests/golden/full4096.npz: the reference's DragPose.run,
+    frame by frame, in fp32 and in fp64)."""
     from dragposer_amd.optimizer import to_device_batch
 
     m = R.OracleModel()
     b = R.synth_inputs(m, 4096)
+    ref = R.load_golden(os.path.join(golden_dir, "full4096.npz"))
+    assert _inputs_digest(b) == ref["meta"]["digest"], "the recipe's inputs are not the ones the reference was run on"
     d = to_device_batch(b, dev)
     o1 = {k: v.cpu().numpy() for k, v in opt.optimize(**d, n_iter=50).items()}
     o2 = {k: v.cpu().numpy() for k, v in opt.optimize(**d, n_iter=50).items()}
@@ -212,20 +241,25 @@ def test_full_size_batch_properties(opt, dev):
     dp = to_device_batch({k: b[k][perm] for k in KEYS}, dev)
     o3 = opt.optimize(**dp, n_iter=50)
     np.testing.assert_array_equal(o3["z"].cpu().numpy(), o1["z"][perm])
-    # Every well-conditioned frame within 0.05 mm of the fp32 oracle.  Ill-conditioned frames (module docstring; between
-    # the CPU oracles on this very batch: frames 1657 and 3893, 0.39 and 0.66 mm) plus at most one frame that is
-    # borderline for the GPU's rounding but not for the CPU pair's: <= 5 mm, and every frame that uses the allowance must
-    # show the mechanism -- a LeakyReLU pre-activation within fp32 rounding of zero on its fp64 trajectory.
-    sens, ref = _sensitive_frames(b, 50, 0.02)
-    err = _mm(o1["pos"], ref["pos"]).max(axis=1)
+    # Every frame against the reference.  The loss's gradient is discontinuous where a LeakyReLU pre-activation crosses zero
+    # (module docstring): on a frame whose trajectory takes one within fp32 rounding of zero, two correct implementations part
+    # ways -- the reference's own fp32 and fp64 runs do on 1 of these 4096 frames (frame 2327, 3.2 mm), each other pair of
+    # implementations on its own one or two.  So: at most 4 frames (0.1 %) above 0.05 mm, none above 5 mm, and every one of them
+    # either reference-flagged or showing the mechanism (|pre-activation| < 5e-6 on its fp64 trajectory; typical frames 3e-4).
+    e = _mm(o1["pos"], ref["pos"])
+    err = e.max(axis=1)
+    ref_flag = np.zeros(4096, bool)
+    ref_flag[ref["sens_frames"]] = True
     allowance = np.nonzero(err > 0.05)[0]
-    extra = [f for f in allowance if not sens[f]]
     kink = _kink_distance(b, allowance, 50, 0.02)
-    print(f"4096 frames: oracle-flagged {np.nonzero(sens)[0].tolist()}, above 0.05 mm {allowance.tolist()} "
-          f"(errors {np.round(err[allowance], 3).tolist()} mm, smallest |pre-activation| {kink.tolist()}), not flagged by the oracle pair: {extra}")
-    assert sens.sum() <= 4 and len(allowance) <= 4 and len(extra) <= 1 and err.max() <= 5.0, (sens.sum(), allowance, err.max())
-    assert (kink < 5e-6).all(), kink  # typical frames: 1.5e-5 (5 % quantile) ... 3e-4 (median)
+    print(f"4096 frames vs the reference's fp32 run: mean {e.mean():.5f} mm, p99 {np.percentile(e, 99):.5f}, p99.9 {np.percentile(e, 99.9):.5f}, max {e.max():.3f}; "
+          f"above 0.05 mm: frames {allowance.tolist()} ({np.round(err[allowance], 3).tolist()} mm, smallest |pre-activation| {kink.tolist()}); "
+          f"the reference's own fp32 vs fp64 runs: frames {ref['sens_frames'].tolist()} ({np.round(ref['ref32_vs_ref64_mm'][ref['sens_frames']], 3).tolist()} mm)")
+    assert len(allowance) <= 4 and err.max() <= 5.0, (allowance, err.max())
+    assert all(ref_flag[f] or k < 5e-6 for f, k in zip(allowance, kink)), (allowance, kink)
     assert np.percentile(err, 99.8) <= 0.05 and err[err <= 0.05].mean() <= 0.002, (np.percentile(err, 99.8), err.mean())
+    np.testing.assert_allclose(o1["z"][err <= 0.05], ref["z_final"][err <= 0.05], atol=5e-5)
+    np.testing.assert_allclose(o1["loss"][err <= 0.05], ref["loss_last"][err <= 0.05], rtol=2e-3, atol=1e-8)
     first = opt.optimize(**d, n_iter=1)["loss"].cpu().numpy().sum(1)
     assert (o1["loss"].sum(1) < first).mean() > 0.99
     assert np.isfinite(o1["z"]).all()
