@@ -132,8 +132,9 @@ DEV f4 lrelu_factor16(f4 x)
 DEV f4 bias_row(const float* lds_bias, int tile, int g) { return *(const f4*)(lds_bias + (tile * 4 + g) * 4); }
 
 // ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) void dp_w16_kernel(const KArgs a)
+// NW waves per workgroup, WPS waves per SIMD (register budget 512 / WPS): one workgroup per CU either way (the LDS image).
+template <int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[L16_END];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -450,11 +451,18 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w16_kernel(const KArgs a)
     }
 }
 
-extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream)
+// One wave per SIMD (4 waves, 64 frames per workgroup) until every SIMD of the chip has a wave; beyond that two waves per SIMD
+// (8 waves, 128 frames per workgroup): the matrix phases of one wave run under the vector phases of the other.
+extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int n_cu, int force_waves)
 {
-    constexpr int NW = 4;
-    const int grid = (args->n_frames + NW * FPW - 1) / (NW * FPW);
-    hipLaunchKernelGGL((dp_w16_kernel<NW>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    const bool two = force_waves ? force_waves == 8 : args->n_frames > n_cu * 4 * FPW;
+    if (two) {
+        const int grid = (args->n_frames + 8 * FPW - 1) / (8 * FPW);
+        hipLaunchKernelGGL((dp_w16_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, *args);
+    } else {
+        const int grid = (args->n_frames + 4 * FPW - 1) / (4 * FPW);
+        hipLaunchKernelGGL((dp_w16_kernel<4, 1>), dim3(grid), dim3(256), 0, stream, *args);
+    }
     return hipGetLastError();
 }
 

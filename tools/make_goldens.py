@@ -352,8 +352,8 @@ def add_f64(name, gold, offsets, parents, workers):
 
 def full_size_reference(name, B, seed, gold, offsets, parents, workers):
     """BASELINE's headline batch (recipe S1, B frames, 50 iterations, inputs exactly as tests/bench.py draw them through
-    oracle.ref_torch.synth_inputs) through the REAL reference in fp32 and in fp64.  The fixture holds no inputs (the tests
-    re-draw them and check the digest), the fp32 reference positions / latents of every frame, per frame the distance between
+    oracle.ref_torch.synth_inputs) through the REAL reference in fp32 and in fp64.  The fixture holds the tracked joints' targets
+    (the tests re-draw the rest and check the digest of everything), the fp32 reference positions / latents of every frame, per frame the distance between
     the reference's own fp32 and fp64 runs, and the fp64 positions of the frames where that distance exceeds 0.02 mm."""
     sys.path.insert(0, REPO)
     from oracle import ref_torch as R  # inputs only: the recipe the GPU tests and bench.py use
@@ -365,7 +365,9 @@ def full_size_reference(name, B, seed, gold, offsets, parents, workers):
     sens = np.nonzero(d > 0.02)[0].astype(np.int32)
     meta = dict(name=name, B=B, seed=seed, n_iter=50, lambda_tmp=0.02, digest=inputs_digest(inp), torch=torch.__version__)
     path = os.path.join(gold, f"{name}.npz")
+    T6 = [0, 3, 7, 13, 17, 21]  # the targets travel with the fixture: they come out of CPU matrix products whose last bits differ between hosts
     np.savez_compressed(path, pos=o32["pos"], z_final=o32["z_final"], z_pre=o32["z_pre"], loss_last=o32["loss_last"].astype(np.float32),
+                        tgt_pos6=inp["tgt_pos"][:, T6], tgt_rot6=inp["tgt_rot"][:, T6],
                         ref32_vs_ref64_mm=d, sens_frames=sens, pos_f64_sens=o64["pos"][sens], z_final_f64_sens=o64["z_final"][sens],
                         meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
     print(f"wrote {path} {os.path.getsize(path)} bytes; reference fp32 vs fp64 > 0.02 mm on frames {sens.tolist()} ({np.round(d[sens], 3).tolist()} mm)")
