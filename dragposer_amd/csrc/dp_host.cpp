@@ -590,6 +590,8 @@ static int launch(dp_ctx* ctx, KArgs& k, void* stream, int kernel = DP_KERNEL_W4
 #else
     if (kernel == DP_KERNEL_W16) ctx->last_kernel = 16;
     static const int w16_waves = [] { const char* e = std::getenv("DP_W16_WAVES"); return e ? std::atoi(e) : 0; }(); // diagnostic: 4 or 8 (A/B runs)
+    static const int w16_stagger = [] { const char* e = std::getenv("DP_W16_STAGGER"); return e ? std::atoi(e) : 6; }();
+    k.w16_stagger = w16_stagger;
     hipError_t e = kernel == DP_KERNEL_W16 ? dp_launch_w16(&k, (hipStream_t)stream, ctx->n_cu, w16_waves) : dp_launch_w4(&k, (hipStream_t)stream);
 #endif
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));

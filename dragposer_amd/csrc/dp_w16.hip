@@ -106,22 +106,52 @@ DEV B3 split_block(f4 t0, f4 t1)
 }
 DEV f4 mm(u4 a, u4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0); }
 
-// output tile N of product LAYER: acc (bias or zero) + sum over the K-blocks of W x; the six term pairs, small ones first
-template <int LAYER, int N> DEV f4 out_tile(const u4* img, f4 acc, const B3* b)
+// The weights of one (output tile, K-block) pair: three ds_read_b128 (the bf16 terms of the same 16 x 32 block).  The 45 pairs of an
+// iteration are consumed in a fixed order, so every pair's reads are ISSUED ONE PAIR AHEAD of its six MFMAs (a lone wave otherwise
+// sits out an LDS round trip per pair: 4.8 k of 16 k cycles per iteration waiting at s_waitcnt, profiles/r03_w16_pmc_first.txt).
+struct W3 { u4 h, m, l; };
+template <int PAIR> DEV W3 wload(const u4* img)
 {
+    const u4* w = img + PAIR * (N_TERMS * 64);
+    W3 r;
+    r.h = w[0]; r.m = w[64]; r.l = w[128];
+    return r;
+}
+// pins the reads above this point (vector and matrix arithmetic may still move across; LDS operations may not)
+DEV void pin_reads() { __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x400); }
+// one pair: acc += W x, the six term products above 2^-24, small ones first
+DEV f4 pair_mm(f4 acc, const W3& w, const B3& b)
+{
+    acc = mm(w.l, b.t[0], acc);
+    acc = mm(w.m, b.t[1], acc);
+    acc = mm(w.h, b.t[2], acc);
+    acc = mm(w.m, b.t[0], acc);
+    acc = mm(w.h, b.t[1], acc);
+    acc = mm(w.h, b.t[0], acc);
+    return acc;
+}
+// output tile N of product LAYER.  PREF (one wave per SIMD): from weights `w` of its first pair (already in flight); leaves the
+// first pair of NEXT in `w`.  !PREF (two waves per SIMD: the partner covers the LDS latency, and registers are short): read at use.
+template <int LAYER, int N, int NEXT, bool PREF> DEV f4 out_tile(const u4* img, W3& w, f4 acc, const B3* b)
+{
+    constexpr int P0 = PAIR0[LAYER] + N * NKB[LAYER];
 #pragma unroll
     for (int kb = 0; kb < NKB[LAYER]; ++kb) {
-        const u4* w = img + (PAIR0[LAYER] + N * NKB[LAYER] + kb) * (N_TERMS * 64);
-        const u4 wh = w[0], wm = w[64], wl = w[128];
-        acc = mm(wl, b[kb].t[0], acc);
-        acc = mm(wm, b[kb].t[1], acc);
-        acc = mm(wh, b[kb].t[2], acc);
-        acc = mm(wm, b[kb].t[0], acc);
-        acc = mm(wh, b[kb].t[1], acc);
-        acc = mm(wh, b[kb].t[0], acc);
+        if (PREF) {
+            W3 nx;
+            if (kb + 1 < NKB[LAYER]) nx = kb == 0 ? wload<P0 + 1>(img) : wload<P0 + 2>(img);
+            else nx = wload<NEXT>(img);
+            pin_reads();
+            acc = pair_mm(acc, w, b[kb]);
+            w = nx;
+        } else {
+            const W3 wc = kb == 0 ? wload<P0>(img) : kb == 1 ? wload<P0 + 1>(img) : wload<P0 + 2>(img);
+            acc = pair_mm(acc, wc, b[kb]);
+        }
     }
     return acc;
 }
+constexpr int pair_of(int layer, int n) { return PAIR0[layer] + n * NKB[layer]; }
 
 DEV f4 lrelu_factor16(f4 x)
 { // x > 0 ? 1 : 0.2 as med3(x * 2^127, 0.2, 1) (dp_w4.hip)
@@ -208,6 +238,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 
     __syncthreads();
     if (f0 >= nB) return; // (uniform per wave; no barrier below)
+    // Two waves per SIMD run the same program; released together by the barrier they would meet in the same phase every
+    // iteration -- matrix work beside matrix work, vector beside vector.  The second half of the workgroup (the partners of waves
+    // 0..3) starts late by about half an iteration, so that one wave's matrix phases fall on the other's vector phases.
+    if (WPS == 2 && wave >= NW / 2)
+        for (int k = 0; k < a.w16_stagger; ++k) __builtin_amdgcn_s_sleep(16);
 
     const float* lbias = (const float*)lds + L16_BIAS;
     Q4 q[NTY];       // unit quaternions of my slots (displacement slot: the de-normalised displacement in w, x, y)
@@ -229,30 +264,33 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         // ================= forward: a0 = lrelu(A0 z + c0), a1 = lrelu(A1 a0 + b1), y = A2' a1 + b2'
         f4 fac0[3], fac1[4], y[NTY];
         B3 bz[1], b0[2], b1[2];
+        constexpr bool PREF = WPS == 1;
+        W3 wq;
+        if (PREF) wq = wload<pair_of(L0, 0)>(img);
         bz[0] = split_block(z[0], z[1]);
         f4 a0[3], a1[4];
-        a0[0] = out_tile<L0, 0>(img, bias_row(lbias, 0, g), bz);
-        a0[1] = out_tile<L0, 1>(img, bias_row(lbias, 1, g), bz);
-        a0[2] = out_tile<L0, 2>(img, bias_row(lbias, 2, g), bz);
+        a0[0] = out_tile<L0, 0, pair_of(L0, 1), PREF>(img, wq, bias_row(lbias, 0, g), bz);
+        a0[1] = out_tile<L0, 1, pair_of(L0, 2), PREF>(img, wq, bias_row(lbias, 1, g), bz);
+        a0[2] = out_tile<L0, 2, pair_of(L1, 0), PREF>(img, wq, bias_row(lbias, 2, g), bz);
 #pragma unroll
         for (int n = 0; n < 3; ++n) { fac0[n] = lrelu_factor16(a0[n]); a0[n] = a0[n] * fac0[n]; }
         b0[0] = split_block(a0[0], a0[1]);
         b0[1] = split_block(a0[2], f4{0.f, 0.f, 0.f, 0.f});
-        a1[0] = out_tile<L1, 0>(img, bias_row(lbias, 3, g), b0);
-        a1[1] = out_tile<L1, 1>(img, bias_row(lbias, 4, g), b0);
-        a1[2] = out_tile<L1, 2>(img, bias_row(lbias, 5, g), b0);
-        a1[3] = out_tile<L1, 3>(img, bias_row(lbias, 6, g), b0);
+        a1[0] = out_tile<L1, 0, pair_of(L1, 1), PREF>(img, wq, bias_row(lbias, 3, g), b0);
+        a1[1] = out_tile<L1, 1, pair_of(L1, 2), PREF>(img, wq, bias_row(lbias, 4, g), b0);
+        a1[2] = out_tile<L1, 2, pair_of(L1, 3), PREF>(img, wq, bias_row(lbias, 5, g), b0);
+        a1[3] = out_tile<L1, 3, pair_of(L2, 4), PREF>(img, wq, bias_row(lbias, 6, g), b0);
 #pragma unroll
         for (int n = 0; n < 4; ++n) { fac1[n] = lrelu_factor16(a1[n]); a1[n] = a1[n] * fac1[n]; }
         b1[0] = split_block(a1[0], a1[1]);
         b1[1] = split_block(a1[2], a1[3]);
         // the B chain's tiles first: the other chains wait for its quaternions
-        y[4] = out_tile<L2, 4>(img, bias_row(lbias, 11, g), b1);
-        y[5] = out_tile<L2, 5>(img, bias_row(lbias, 12, g), b1);
-        y[0] = out_tile<L2, 0>(img, bias_row(lbias, 7, g), b1);
-        y[1] = out_tile<L2, 1>(img, bias_row(lbias, 8, g), b1);
-        y[2] = out_tile<L2, 2>(img, bias_row(lbias, 9, g), b1);
-        y[3] = out_tile<L2, 3>(img, bias_row(lbias, 10, g), b1);
+        y[4] = out_tile<L2, 4, pair_of(L2, 5), PREF>(img, wq, bias_row(lbias, 11, g), b1);
+        y[5] = out_tile<L2, 5, pair_of(L2, 0), PREF>(img, wq, bias_row(lbias, 12, g), b1);
+        y[0] = out_tile<L2, 0, pair_of(L2, 1), PREF>(img, wq, bias_row(lbias, 7, g), b1);
+        y[1] = out_tile<L2, 1, pair_of(L2, 2), PREF>(img, wq, bias_row(lbias, 8, g), b1);
+        y[2] = out_tile<L2, 2, pair_of(L2, 3), PREF>(img, wq, bias_row(lbias, 9, g), b1);
+        y[3] = out_tile<L2, 3, pair_of(B2, 0), PREF>(img, wq, bias_row(lbias, 10, g), b1); // (bL2's first block rides through the kinematics)
 
         // ================= stage J: normalise, bones, positions relative to the root
 #pragma unroll
@@ -376,19 +414,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         by[2] = split_block(gy[4], gy[5]);
         const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f4 d1[4], d0[3], gz[2];
-        d1[0] = out_tile<B2, 0>(img, zero4, by) * fac1[0];
-        d1[1] = out_tile<B2, 1>(img, zero4, by) * fac1[1];
-        d1[2] = out_tile<B2, 2>(img, zero4, by) * fac1[2];
-        d1[3] = out_tile<B2, 3>(img, zero4, by) * fac1[3];
+        d1[0] = out_tile<B2, 0, pair_of(B2, 1), PREF>(img, wq, zero4, by) * fac1[0];
+        d1[1] = out_tile<B2, 1, pair_of(B2, 2), PREF>(img, wq, zero4, by) * fac1[1];
+        d1[2] = out_tile<B2, 2, pair_of(B2, 3), PREF>(img, wq, zero4, by) * fac1[2];
+        d1[3] = out_tile<B2, 3, pair_of(B1, 0), PREF>(img, wq, zero4, by) * fac1[3];
         bd1[0] = split_block(d1[0], d1[1]);
         bd1[1] = split_block(d1[2], d1[3]);
-        d0[0] = out_tile<B1, 0>(img, zero4, bd1) * fac0[0];
-        d0[1] = out_tile<B1, 1>(img, zero4, bd1) * fac0[1];
-        d0[2] = out_tile<B1, 2>(img, zero4, bd1) * fac0[2];
+        d0[0] = out_tile<B1, 0, pair_of(B1, 1), PREF>(img, wq, zero4, bd1) * fac0[0];
+        d0[1] = out_tile<B1, 1, pair_of(B1, 2), PREF>(img, wq, zero4, bd1) * fac0[1];
+        d0[2] = out_tile<B1, 2, pair_of(B0, 0), PREF>(img, wq, zero4, bd1) * fac0[2];
         bd0[0] = split_block(d0[0], d0[1]);
         bd0[1] = split_block(d0[2], zero4);
-        gz[0] = out_tile<B0, 0>(img, zero4, bd0) + a.ctmp * (z[0] - zt[0]);
-        gz[1] = out_tile<B0, 1>(img, zero4, bd0) + a.ctmp * (z[1] - zt[1]);
+        gz[0] = out_tile<B0, 0, pair_of(B0, 1), PREF>(img, wq, zero4, bd0) + a.ctmp * (z[0] - zt[0]);
+        gz[1] = out_tile<B0, 1, pair_of(L0, 0), PREF>(img, wq, zero4, bd0) + a.ctmp * (z[1] - zt[1]); // (the last read is a dummy: the next iteration re-reads it)
         if (a.dbg && iter == 0 && fvalid) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
