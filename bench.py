@@ -36,11 +36,13 @@ TRACK6 = [0, 3, 7, 13, 17, 21]
 W6 = {0: (10.0, 10.0), 3: (5.0, 0.01), 7: (5.0, 0.01), 13: (5.0, 0.01), 17: (5.0, 0.01), 21: (5.0, 0.01)}
 
 
-def synth_on_device(opt, B, seed, device, lo=0, hi=None):
+def synth_on_device(opt, B, seed, device, lo=0, hi=None, mixed=False):
     """Recipe S, targets = FK(decode(Zs), CR) computed by the product's own forward kernel.  [lo, hi): this rank's
-    shard of the B-frame batch (every rank draws the same batch and keeps its rows)."""
+    shard of the B-frame batch (every rank draws the same batch and keeps its rows).  mixed: recipe S4, every
+    frame tracks its own 1..6 of the six joints."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     hi = B if hi is None else hi
+    Ball = B
     Zs = (torch.randn(B, 24, generator=g) * 0.3)[lo:hi]
     Z0 = (torch.randn(B, 24, generator=g) * 0.3)[lo:hi]
     ZT = Z0 + (0.05 * torch.randn(B, 24, generator=g))[lo:hi]
@@ -49,7 +51,14 @@ def synth_on_device(opt, B, seed, device, lo=0, hi=None):
     B = hi - lo
     w = torch.zeros(B, 22, 2)
     tracked = torch.zeros(B, 22, dtype=torch.uint8)
-    for j, wj in W6.items():
+    if mixed:  # (vectorised stand-in for the recipe's per-frame randperm: same distribution, drawn from the same generator)
+        Eb = torch.randint(1, 7, (Ball,), generator=g)[lo:hi]
+        order = torch.argsort(torch.rand(Ball, 6, generator=g), dim=1)[lo:hi]
+        keep = order < Eb[:, None]
+        for k, j in enumerate(TRACK6):
+            tracked[:, j] = keep[:, k].to(torch.uint8)
+            w[:, j] = torch.tensor(W6[j]) * keep[:, k, None]
+    for j, wj in (() if mixed else W6.items()):
         w[:, j] = torch.tensor(wj)
         tracked[:, j] = 1
     Zs, Z0, ZT, CR, w, tracked = (t.to(device).contiguous() for t in (Zs, Z0, ZT, CR, w, tracked))
@@ -120,6 +129,9 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU (weak scaling)")
     ap.add_argument("--total-frames", type=int, default=0, help="one batch of this many frames sharded over the GPUs (strong scaling)")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--config", default="s1", choices=["s1", "s4"],
+                    help="s1: BASELINE's headline workload (6 trackers, fp32); s4: BASELINE config 5 (1-6 trackers per frame, bf16-rounded decoder weights)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "w4", "w16"], help="include/dragposer.h: DP_KERNEL_*")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -151,19 +163,20 @@ def main():
 
     from dragposer_amd.sharding import reduce_stats, shard_bounds
 
-    opt = LatentOptimizer(device=device)
+    s4 = args.config == "s4"
+    opt = LatentOptimizer(device=device, weight_dtype="bf16" if s4 else "fp32")
     N = args.iters
     if args.total_frames > 0:  # strong scaling: contiguous shards of ONE batch
         lo, hi = shard_bounds(args.total_frames, world, rank)
         if hi <= lo:
             raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
-        batch = synth_on_device(opt, args.total_frames, 1234, device, lo, hi)
+        batch = synth_on_device(opt, args.total_frames, 1234, device, lo, hi, mixed=s4)
         B, total_per_step = hi - lo, args.total_frames
     else:  # weak scaling: every rank its own batch of --frames
-        batch = synth_on_device(opt, args.frames, 1234 + rank, device)
+        batch = synth_on_device(opt, args.frames, 1234 + rank, device, mixed=s4)
         B, total_per_step = args.frames, args.frames * world
     names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
-    out = opt.optimize(**batch, n_iter=N, outputs=names)
+    out = opt.optimize(**batch, n_iter=N, outputs=names, kernel=args.kernel)
     torch.cuda.synchronize()
 
     def barrier():
@@ -171,14 +184,14 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=args.kernel)
     barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream the kernel is launched on
     for _ in range(args.steps):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out)
+        opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=args.kernel)
     ev1.record()
     torch.cuda.synchronize()
     barrier()
@@ -193,13 +206,16 @@ def main():
 
         nb = min(256, B)
         cpu = {k: v[:nb].cpu().numpy() for k, v in batch.items()}
-        ref = AnalyticOracle(precision="f32").optimize(cpu["z0"], cpu["z_tgt"], cpu["cur_rot"], cpu["tgt_pos"],
+        ref = AnalyticOracle(precision="f32", weight_rounding="bf16" if s4 else "none").optimize(cpu["z0"], cpu["z_tgt"], cpu["cur_rot"], cpu["tgt_pos"],
                                                        cpu["tgt_rot"], cpu["w"], cpu["tracked"], N)
         e = np.linalg.norm(out["pos"][:nb].cpu().numpy() - ref["pos"], axis=-1) * 1000.0
         err_mm = float(np.percentile(e, 99))
 
     # the only collective of the job: one MAX-reduction of three doubles (RCCL over xGMI; gloo in the rehearsal)
+    kern_ms_rank = kern_ms
     (dt, kern_ms, err_mm), _ = reduce_stats(dist, device, max_stats=[dt, kern_ms, err_mm if err_mm == err_mm else -1.0])
+    if world > 1:  # every rank's own launch time, on stderr (rank 0's JSON line carries the maximum)
+        print(f"[rank {rank}] kernel_ms {kern_ms_rank:.4f} frames {B}", file=sys.stderr, flush=True)
 
     if rank == 0:
         value = total_per_step * args.steps / dt
@@ -217,18 +233,20 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.total_frames > 0 else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("bf16 weights (three bf16 terms per folded fp32 entry) x fp32 activations (three bf16 terms), fp32 accumulate" if fpb >= 64 else "f32"),
             "data": "synthetic",
-            "config": {"workload": (f"S1: ONE batch of {total_per_step} synthetic frames" if args.total_frames > 0 else
-                                    f"S1: {B} synthetic frames per GPU") + f", 6 trackers [0,3,7,13,17,21], {N} Adam iters/frame, fp32 "
-                                   f"(BASELINE north_star: 4096-frame batch)",
+            "config": {"workload": ((f"{'S4' if s4 else 'S1'}: ONE batch of {total_per_step} synthetic frames" if args.total_frames > 0 else
+                                     f"{'S4' if s4 else 'S1'}: {B} synthetic frames per GPU") +
+                                    (f", 1-6 of the trackers [0,3,7,13,17,21] per frame (masked loss), bf16-rounded decoder weights, {N} Adam iters/frame (BASELINE config 5)"
+                                     if s4 else f", 6 trackers [0,3,7,13,17,21], {N} Adam iters/frame, fp32 (BASELINE north_star: 4096-frame batch)")),
                        "frames_per_gpu": Bk, "frames_total": total_per_step, "iters": N,
                        "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(Bk, N),
                          "traffic_note": f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes "
                                          f"({PMC_FILE}, same command); algorithmic {Bk * 2326:.3g}",
-                         "kernel": "dp_optimize_kernel<false>" if tpb == 512 else "dp_w4_kernel<4, false>", "kernel_ms": kern_ms,
+                         "kernel": {16: "dp_w4_kernel<4, false>", 64: "dp_w16_kernel<4, 1>", 128: "dp_w16_kernel<8, 2>"}.get(fpb, "?"), "kernel_ms": kern_ms,
+                         "frac_of_bf16_mfma_peak_2.5PF": (achieved / 2.5e15 if fpb >= 64 else None),
                          "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},
                          "flop_per_launch": Bk * N * FLOP_PER_FRAME_ITER,
                          "hbm_algorithmic_GBps": Bk * 2326 / (kern_ms * 1e-3) / 1e9},

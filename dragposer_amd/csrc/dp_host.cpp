@@ -547,9 +547,10 @@ extern "C" int dp_kernel_geometry(const dp_ctx* ctx, int* frames_per_block, int*
     if (threads_per_block) *threads_per_block = NTHREADS;
     if (lds_bytes) *lds_bytes = dp_kernel_lds_bytes();
 #else
-    const bool k16 = ctx && ctx->last_kernel == 16;
-    if (frames_per_block) *frames_per_block = k16 ? dp_w16_frames_per_block() : dp_w4_frames_per_block();
-    if (threads_per_block) *threads_per_block = 256;
+    const int w16w = ctx && ctx->last_kernel >= 16 ? ctx->last_kernel / 4 : 0; // waves per workgroup of the last dp_w16 launch
+    const bool k16 = w16w != 0;
+    if (frames_per_block) *frames_per_block = k16 ? w16w * dp_w16_frames_per_wave() : dp_w4_frames_per_block();
+    if (threads_per_block) *threads_per_block = k16 ? w16w * 64 : 256;
     if (lds_bytes) *lds_bytes = k16 ? dp_w16_lds_bytes() : dp_w4_lds_bytes();
 #endif
     return DP_OK;
@@ -588,11 +589,12 @@ static int launch(dp_ctx* ctx, KArgs& k, void* stream, int kernel = DP_KERNEL_W4
     (void)kernel;
     hipError_t e = dp_launch_optimize(&k, (hipStream_t)stream);
 #else
-    if (kernel == DP_KERNEL_W16) ctx->last_kernel = 16;
-    static const int w16_waves = [] { const char* e = std::getenv("DP_W16_WAVES"); return e ? std::atoi(e) : 0; }(); // diagnostic: 4 or 8 (A/B runs)
-    static const int w16_stagger = [] { const char* e = std::getenv("DP_W16_STAGGER"); return e ? std::atoi(e) : 6; }();
-    k.w16_stagger = w16_stagger;
-    hipError_t e = kernel == DP_KERNEL_W16 ? dp_launch_w16(&k, (hipStream_t)stream, ctx->n_cu, w16_waves) : dp_launch_w4(&k, (hipStream_t)stream);
+    // dp_w16: one wave per SIMD (4 waves, 64 frames per workgroup) until every SIMD of the chip has a wave; beyond that two
+    // (8 waves, 128 frames per workgroup): one wave's matrix phases under the other's vector phases
+    const int w16_waves = k.n_frames > ctx->n_cu * 4 * dp_w16_frames_per_wave() ? 8 : 4;
+    if (kernel == DP_KERNEL_W16) ctx->last_kernel = 16 * (w16_waves / 4);
+    k.w16_stagger = 0; // (a start delay for the second half of the waves: measured, no effect -- profiles/r03_w16_stagger.txt)
+    hipError_t e = kernel == DP_KERNEL_W16 ? dp_launch_w16(&k, (hipStream_t)stream, w16_waves) : dp_launch_w4(&k, (hipStream_t)stream);
 #endif
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));
     return DP_OK;

@@ -52,8 +52,8 @@ extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream);
 extern "C" int dp_w4_lds_bytes(void);
 extern "C" int dp_w4_frames_per_block(void);
 // dp_w16.hip: 16 frames per wave, decoder on v_mfma_f32_16x16x32_bf16 in split precision (fixed iteration count only)
-extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int n_cu, int force_waves);
+extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int waves /* 4 or 8 per workgroup */);
 extern "C" int dp_w16_lds_bytes(void);
-extern "C" int dp_w16_frames_per_block(void);
+extern "C" int dp_w16_frames_per_wave(void);
 extern "C" int dp_w16_supported(const dp_model* m);
 extern "C" int dp_debug_pack_w16(const dp_folded* f, const dp_model* m, unsigned* img, float* bias, void* slots_out);

@@ -491,10 +491,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 
 // One wave per SIMD (4 waves, 64 frames per workgroup) until every SIMD of the chip has a wave; beyond that two waves per SIMD
 // (8 waves, 128 frames per workgroup): the matrix phases of one wave run under the vector phases of the other.
-extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int n_cu, int force_waves)
+extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int waves)
 {
-    const bool two = force_waves ? force_waves == 8 : args->n_frames > n_cu * 4 * FPW;
-    if (two) {
+    if (waves == 8) {
         const int grid = (args->n_frames + 8 * FPW - 1) / (8 * FPW);
         hipLaunchKernelGGL((dp_w16_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, *args);
     } else {
@@ -505,4 +504,4 @@ extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int n
 }
 
 extern "C" int dp_w16_lds_bytes(void) { return L16_END * 4; }
-extern "C" int dp_w16_frames_per_block(void) { return 4 * FPW; }
+extern "C" int dp_w16_frames_per_wave(void) { return FPW; }

@@ -1,13 +1,15 @@
 """`eval_drag` on MI355X: the reference's offline evaluation CLI (python/src/eval_drag.py:21-293) with the
 per-frame optimisation running in the HIP kernel.
 
-    python -m dragposer_amd.eval_drag [model.npz] input.bvh --config config/6_trackers_config.json
+    python -m dragposer_amd.eval_drag models/model_dancedb data/example/eval/example.bvh --config config/6_trackers_config.json
 
-Same positional arguments / --config / --verbose and the same JSON keys as the reference.  Differences,
-all stated in the output: the model is the flat fixture (tensors of generator.pt + data.pt), and because the
-reference's temporal.pt is not distributed with it the temporal predictor is optional: without
---temporal-checkpoint the pull term is switched off (lambda_temporal = 0) instead of pulling towards the
-predictions of an untrained network.
+The reference's contract: `model_path` is the model FOLDER (generator.pt, data.pt and -- when trained -- temporal.pt, as
+train.py / train_temporal.py save them), `input_path` a .bvh file or a directory of them, --config / --verbose as there, the
+result written to data/eval_<name> relative to the working directory, and the reference's four result lines printed
+verbatim (eval_drag.py:249-252).  Also accepted as `model_path`: this package's flat .npz fixture (default: the shipped
+model_dancedb).  Stated in the output: because the reference's temporal.pt is not distributed with it the temporal
+predictor is optional -- without one (no temporal.pt in the folder, no --temporal-checkpoint) the pull term is switched off
+(lambda_temporal = 0) instead of pulling towards the predictions of an untrained network.
 """
 import argparse
 import json
@@ -21,7 +23,7 @@ from . import quat_np as Q
 from .bvh import BVH
 from .drag_pose import DragPose
 from .encoder import PoseEncoder
-from .model import DEFAULT_MODEL, NJ
+from .model import DEFAULT_MODEL, NJ, load_model_arrays
 from .motion import local_quats_from_bvh, prepare_motion
 from .optimizer import LatentOptimizer
 from .temporal import load_reference_checkpoint
@@ -162,7 +164,9 @@ def evaluate_file(args, input_path, opt, encoder, temporal_pack, cfg, raw):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Evaluate DragPoser (HIP backend)")
-    ap.add_argument("model_path", nargs="?", default=DEFAULT_MODEL, help="model fixture (.npz); default: the shipped model_dancedb")
+    ap.add_argument("model_path", nargs="?", default=DEFAULT_MODEL,
+                    help="path to pytorch model folder (generator.pt, data.pt[, temporal.pt]) as the reference takes it, or a model fixture (.npz); "
+                         "default: the shipped model_dancedb")
     ap.add_argument("input_path", help=".bvh file or a directory of .bvh files")
     ap.add_argument("--config", default=None, help="tracker config JSON (same keys as the reference's config/*.json)")
     ap.add_argument("--temporal-checkpoint", default=None, help="temporal.pt as saved by the reference's train_temporal.py")
@@ -183,16 +187,21 @@ def main(argv=None):
     if args.config is not None:
         with open(args.config) as f:
             cfg = json.load(f)
-    raw = np.load(args.model_path)
-    opt = LatentOptimizer(args.model_path, device=args.device)
-    encoder = PoseEncoder(args.model_path).to(opt.device)
-    if args.temporal_checkpoint is not None:
-        temporal_pack = load_reference_checkpoint(args.temporal_checkpoint, opt.device)
-    else:
-        temporal_pack = (None, np.zeros(24, np.float32), np.ones(24, np.float32))
     files = [args.input_path]
     if os.path.isdir(args.input_path):
         files = sorted(os.path.join(args.input_path, f) for f in os.listdir(args.input_path) if f.endswith(".bvh"))
+        if not files:
+            raise SystemExit(f"{args.input_path}: no .bvh files")
+    raw = load_model_arrays(args.model_path, skeleton_bvh=files[0])  # (a model folder carries no skeleton: the evaluated BVH's, train.py:329-341)
+    opt = LatentOptimizer(device=args.device, arrays=raw)
+    encoder = PoseEncoder(arrays=raw).to(opt.device)
+    tck = args.temporal_checkpoint
+    if tck is None and os.path.isdir(args.model_path) and os.path.exists(os.path.join(args.model_path, "temporal.pt")):
+        tck = os.path.join(args.model_path, "temporal.pt")  # train_temporal.load_model (train_temporal.py:474-482)
+    if tck is not None:
+        temporal_pack = load_reference_checkpoint(tck, opt.device)
+    else:
+        temporal_pack = (None, np.zeros(24, np.float32), np.ones(24, np.float32))
     if args.lockstep and len(files) > 1:
         print(f"Evaluate {len(files)} files in lock-step ------------------------")
         return evaluate_files(args, files, opt, encoder, temporal_pack, cfg, raw)

@@ -62,3 +62,37 @@ class HostModel:
         g = lambda name, shape: np.ctypeslib.as_array(getattr(out, name)).reshape(shape).copy()
         return dict(A0=g("A0", (40, 24)), c0=g("c0", (40,)), A1=g("A1", (60, 40)), b1=g("b1", (60,)),
                     A2=g("A2", (92, 60)), b2=g("b2", (92,))), out
+
+
+def load_reference_model_folder(model_dir, skeleton_bvh=None):
+    """The reference CLI's `model_path` (python/src/eval_drag.py:260-264): a FOLDER holding `generator.pt`
+    ({"model_state_dict": state_dict of Generator_Model}, train.py:297-303) and `data.pt` ({"means": {"dqs",
+    "displacement"}, "stds": {...}}, train.py:288-296), plain torch.load-able dicts of tensors -> the array dict HostModel /
+    PoseEncoder read (the keys of data/model_dancedb.npz).  The skeleton is not part of those files: the reference takes
+    parents and offsets from the BVH it evaluates (train.get_info_from_bvh, train.py:329-341), so does this
+    (`skeleton_bvh`: a path or a loaded dragposer_amd.bvh.BVH)."""
+    import torch
+
+    sd = torch.load(os.path.join(model_dir, "generator.pt"), map_location="cpu", weights_only=True)["model_state_dict"]
+    data = torch.load(os.path.join(model_dir, "data.pt"), map_location="cpu", weights_only=True)
+    arrs = {k[len("autoencoder."):] if k.startswith("autoencoder.") else k: v.detach().cpu().numpy() for k, v in sd.items()}
+    for grp in ("means", "stds"):
+        arrs[f"{grp}.dqs"] = data[grp]["dqs"].detach().cpu().numpy().reshape(-1)
+        arrs[f"{grp}.displacement"] = data[grp]["displacement"].detach().cpu().numpy().reshape(-1)
+    if skeleton_bvh is not None:
+        from .bvh import BVH
+
+        bvh = skeleton_bvh if hasattr(skeleton_bvh, "get_data") else BVH().load(skeleton_bvh)
+        _, _, parents, offsets, _ = bvh.get_data()
+        arrs["parents"] = np.asarray(parents, dtype=np.int32).copy()
+        arrs["parents"][0] = 0                                     # train.py:338
+        arrs["offsets"] = np.asarray(offsets, dtype=np.float32).copy()
+        arrs["offsets"][0] = 0.0                                   # train.py:340
+    return arrs
+
+
+def load_model_arrays(model_path, skeleton_bvh=None):
+    """`model_path`: the reference's model folder (above) or this package's flat .npz fixture"""
+    if os.path.isdir(model_path):
+        return load_reference_model_folder(model_path, skeleton_bvh)
+    return dict(np.load(model_path))

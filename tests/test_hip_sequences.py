@@ -188,6 +188,44 @@ def test_config1_full_example(tmp_path):
     assert res["time"] < 5.0  # the reference's CPU loop takes minutes (about 9 frames/s at 50 iterations)
 
 
+def test_cli_with_the_reference_model_folder(tmp_path, capsys, monkeypatch):
+    """The reference's CLI contract (eval_drag.py:255-293): model_path = a FOLDER with generator.pt / data.pt, input_path = a
+    directory of .bvh files, results in data/eval_<name> under the working directory, the four result lines printed verbatim.
+    Run on the other two motion files the reference ships (example_2, example_3; staged like example.bvh)."""
+    import os
+    import shutil
+
+    from dragposer_amd import eval_drag
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    local = os.path.join(root, "tests", "data", "_local")
+    names = ["example_2.bvh", "example_3.bvh"]
+    if not all(os.path.exists(os.path.join(local, n)) for n in names):
+        pytest.skip("example_2 / example_3 not staged (build() copies them where /root/reference is mounted)")
+    raw = np.load(R.DEFAULT_MODEL)
+    folder = tmp_path / "model_dancedb"
+    folder.mkdir()
+    sd = {"autoencoder." + k: torch.tensor(raw[k]) for k in raw.files if k.startswith(("encoder.", "decoder."))}
+    torch.save({"model_state_dict": sd}, folder / "generator.pt")
+    torch.save({"means": {"dqs": torch.tensor(raw["means.dqs"]), "displacement": torch.tensor(raw["means.displacement"])},
+                "stds": {"dqs": torch.tensor(raw["stds.dqs"]), "displacement": torch.tensor(raw["stds.displacement"])}}, folder / "data.pt")
+    inp = tmp_path / "in"
+    inp.mkdir()
+    for n in names:
+        shutil.copyfile(os.path.join(local, n), inp / n)
+    monkeypatch.chdir(tmp_path)  # the reference writes relative to the working directory (train.py:484-509)
+    res = eval_drag.main([str(folder), str(inp), "--config", os.path.join(root, "dragposer_amd", "config", "6_trackers_config.json")])
+    out = capsys.readouterr().out
+    assert len(res) == 2
+    for n, r, frames in zip(names, res, (2920, 3047)):
+        assert r["frames"] == frames and os.path.exists(tmp_path / "data" / ("eval_" + n))
+        assert r["mpjpe"] < 0.045 and r["mpeepe"] < 0.050 and r["mean_iters"] < 40, r  # metres; the paper reports a few cm
+        print(f"{n}: MPJPE {r['mpjpe'] * 1000:.1f} mm, MPEEPE {r['mpeepe'] * 1000:.1f} mm, {r['mean_iters']:.1f} iterations/frame, frame loop {r['time']:.3f} s")
+    for line in ("Evaluate Loss: ", "Mean Per Joint Position Error: ", "Mean End Effector Position Error: ", "Time: "):
+        assert out.count("\n" + line) + out.startswith(line) >= 2, line
+    assert out.count("Evaluate " + str(inp)) == 2 and "------------------------" in out
+
+
 def test_reference_constructor_and_set_initial_pose(golden_dir):
     """the reference's call sequence (eval_drag.py:138,152, run_drag.py:82-96): DragPose(generator_model, temporal_model,
     means_latent, stds_latent, device, device_gpu); set_initial_pose(initial_pose, init_global_pos, initial_global_rot,
