@@ -72,6 +72,17 @@ class DpSeqStep(C.Structure):
     ]
 
 
+class DpSeqFrames(C.Structure):
+    _fields_ = [
+        ("n_steps", C.c_int), ("tgt_pos", C.c_void_p), ("tgt_rot", C.c_void_p), ("tgt_root", C.c_void_p), ("w", C.c_void_p),
+        ("tracked", C.c_void_p), ("z_tgt", C.c_void_p), ("z_tgt_step", C.c_int), ("z_tgt_seq", C.c_int),
+    ]
+
+
+class DpSeqResults(C.Structure):
+    _fields_ = [("pose_ret", C.c_void_p), ("pos_ret", C.c_void_p), ("iters", C.c_void_p), ("loss", C.c_void_p), ("hist_scratch", C.c_void_p)]
+
+
 class DpTemporalLayer(C.Structure):
     _fields_ = [(n, _f) for n in (
         "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
@@ -101,7 +112,7 @@ class DpResult(C.Structure):
 # every symbol include/dragposer.h declares (checked by tests/test_abi.py)
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
-    "dp_forward", "dp_sequence_advance", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
+    "dp_forward", "dp_sequence_advance", "dp_optimize_sequence", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
     "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict",
 )
 
@@ -137,6 +148,8 @@ def load(path=None):
     lib.dp_optimize.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult), C.c_void_p]
     lib.dp_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DpResult), C.c_void_p]
     lib.dp_sequence_advance.argtypes = [C.c_void_p, C.c_int, C.POINTER(DpResult), C.POINTER(DpSeqState), C.POINTER(DpSeqStep), C.c_void_p]
+    lib.dp_optimize_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(DpSeqFrames), C.POINTER(DpParams), C.POINTER(DpSeqState),
+                                         C.POINTER(DpSeqStep), C.POINTER(DpSeqResults), C.c_void_p]
     lib.dp_kernel_geometry.argtypes = [C.c_void_p, _i, _i, _i]
     lib.dp_temporal_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(DpTemporalModel), C.c_int]
     lib.dp_temporal_destroy.argtypes = [C.c_void_p]

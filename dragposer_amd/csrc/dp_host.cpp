@@ -662,6 +662,67 @@ extern "C" int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// n_steps frames of S sequences in one launch (+ one for the history buffers), see include/dragposer.h
+extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const dp_seq_frames* fr, const dp_params* p, const dp_seq_state* st,
+                                    const dp_seq_step* adj, const dp_seq_results* out, void* stream)
+{
+    if (!ctx) return DP_ERR_INVALID;
+#ifdef DP_REF8_BUILD
+    return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize_sequence: not part of the test-only library");
+#else
+    if (n_seq <= 0 || !latent || !fr || !p || !st || !out) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad arguments");
+    if (fr->n_steps <= 0 || !fr->tgt_pos || !fr->tgt_rot || !fr->w || !fr->tracked || !fr->z_tgt)
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: NULL input array / n_steps must be positive");
+    if (!st->global_pos || !st->global_rot || !st->latent_buf || !st->disp_buf || !st->heights_buf || !out->hist_scratch)
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: NULL state array / hist_scratch");
+    if (st->history < 1 || st->n_heights < 0 || st->n_heights > DP_MAX_HEIGHT_JOINTS)
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: history / n_heights out of range");
+    for (int h = 0; h < st->n_heights; ++h)
+        if (st->height_joints[h] < 0 || st->height_joints[h] >= NJ) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad height joint");
+    if (adj && (adj->adjust_joint >= NJ || (adj->adjust_joint >= 0 && (adj->adjust_target_joint < 0 || adj->adjust_target_joint >= NJ))))
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad joint adjustment");
+    if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: n_iter out of range [1,256]");
+    if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad Adam hyper-parameters");
+    KArgs k;
+    fill_model_args(ctx, k);
+    k.z0 = latent; k.z_tgt = fr->z_tgt; k.cur_rot = st->global_rot; k.tgt_pos = fr->tgt_pos; k.tgt_rot = fr->tgt_rot; k.w = fr->w; k.tracked = fr->tracked;
+    k.z = latent; k.pose = out->pose_ret; k.iters = out->iters; k.loss = out->loss;
+    k.n_frames = n_seq; k.n_iter = p->n_iter; k.mode = 0;
+    k.lam_rot = p->lambda_rot; k.lam_tmp = p->lambda_tmp; k.ctmp = 2.f * p->lambda_tmp / 24.f;
+    k.beta2 = p->beta2; k.one_m_b1 = (float)(1.0 - (double)p->beta1); k.one_m_b2 = (float)(1.0 - (double)p->beta2);
+    k.eps = p->eps;
+    k.early_stop = 1;
+    k.stop_eps_pos = p->stop_eps_pos; k.stop_eps_rot = p->stop_eps_rot; k.min_loss_incr = p->min_loss_incr;
+    double b1t = 1.0, b2t = 1.0;
+    for (int t = 0; t < p->n_iter; ++t) {
+        b1t *= (double)p->beta1;
+        b2t *= (double)p->beta2;
+        k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
+        k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
+    }
+    SeqK& q = k.seq;
+    q.n_steps = fr->n_steps; q.z_tgt_step = fr->z_tgt_step; q.z_tgt_seq = fr->z_tgt_seq; q.tgt_root = fr->tgt_root;
+    q.global_pos = st->global_pos; q.global_rot = st->global_rot; q.hist = out->hist_scratch; q.pos_ret = out->pos_ret;
+    q.n_heights = st->n_heights;
+    for (int h = 0; h < st->n_heights; ++h) q.height_joints[h] = st->height_joints[h];
+    q.adjust_joint = adj ? adj->adjust_joint : -1;
+    q.adjust_target_joint = adj ? adj->adjust_target_joint : -1;
+    q.adjust_weight = adj ? adj->adjust_weight : 0.f;
+    for (int c = 0; c < 4; ++c) { q.mean_q0[c] = ctx->mean_q0[c]; q.std_q0[c] = ctx->std_q0[c]; }
+    int rc = launch(ctx, k, stream, DP_KERNEL_W4);
+    if (rc != DP_OK) return rc;
+    DEVICE_GUARD(ctx);
+    HistArgs h;
+    h.n_seq = n_seq; h.n_steps = fr->n_steps; h.history = st->history; h.n_heights = st->n_heights;
+    h.scratch = out->hist_scratch; h.latent_buf = st->latent_buf; h.disp_buf = st->disp_buf; h.heights_buf = st->heights_buf;
+    hipError_t e = dp_launch_sequence_history(&h, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("history launch: ") + hipGetErrorString(e));
+    return DP_OK;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-frame epilogue of S sequences (reference drag_pose.py:369-402), see include/dragposer.h
 extern "C" int dp_sequence_advance(dp_ctx* ctx, int n_seq, const dp_result* res, const dp_seq_state* st, const dp_seq_step* step, void* stream)
 {

@@ -17,6 +17,20 @@ constexpr int DBG_GY = 104;  // [104] dL/dy quads (23.. = virtual items)
 constexpr int DBG_GZ = 208;  // [24] dL/dz (incl. temporal term)
 constexpr int DBG_STRIDE = 240;
 
+struct SeqK { // whole-sequence launches (dp_optimize_sequence): the frame loop of a sequence set inside ONE launch of dp_w4
+    int n_steps;               // 0: an ordinary launch
+    int z_tgt_step, z_tgt_seq; // strides (floats) of z_tgt between steps / between sequences
+    const float* tgt_root;     // [T][S][3] or NULL: position targets of step t are tgt_pos + (tgt_root[t] - current global position)
+    float* global_pos;         // [S][3] in/out
+    float* global_rot;         // [S][4] out (in: KArgs::cur_rot)
+    float* hist;               // [T][S][24 + 3 + NH] history rows of every step: z_pre | root-space displacement (joint adjustment included) | heights
+    float* pos_ret;            // [T][S][3]  returned global position, nullable
+    int n_heights, height_joints[8];
+    int adjust_joint, adjust_target_joint;
+    float adjust_weight;
+    float mean_q0[4], std_q0[4]; // normalisation of the returned pose's root channels
+};
+
 struct KArgs {
     // model (device)
     const float* wfrag;          // [NWAVE][W_REGS][64]  per-wave, per-lane MFMA A operands
@@ -41,6 +55,7 @@ struct KArgs {
     float stop_eps_pos, stop_eps_rot, min_loss_incr;
     float lam_rot, lam_tmp, ctmp; // ctmp = 2 lam_tmp / 24
     float beta2, one_m_b1, one_m_b2, eps;
+    SeqK seq;
     unsigned smask[dpl::NWAVE][dpl::NGEMM]; // bit i: step i of the wave's chain has a non-zero weight block
     AdamTab tab;
 };

@@ -17,3 +17,10 @@ struct SeqArgs {
 };
 
 extern "C" hipError_t dp_launch_sequence_advance(const SeqArgs* args, hipStream_t stream);
+
+struct HistArgs { // appends the rows of n_steps frames to the three history buffers (dp_optimize_sequence's second launch)
+    int n_seq, n_steps, history, n_heights;
+    const float* scratch; // [T][S][24 + 3 + NH]: z_pre | displacement | heights of every step
+    float *latent_buf, *disp_buf, *heights_buf;
+};
+extern "C" hipError_t dp_launch_sequence_history(const HistArgs* args, hipStream_t stream);

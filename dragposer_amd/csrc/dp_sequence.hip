@@ -61,3 +61,25 @@ extern "C" hipError_t dp_launch_sequence_advance(const SeqArgs* args, hipStream_
     hipLaunchKernelGGL(dp_sequence_advance_kernel, dim3(args->n_seq), dim3(64), 0, stream, *args);
     return hipGetLastError();
 }
+
+// The history buffers after n_steps frames (drag_pose.py:384-391, n_steps times): every column shifted by n = min(T, H) and the
+// last n steps appended.  One thread per (sequence, column); reads run ahead of writes.
+__global__ __launch_bounds__(64) void dp_sequence_history_kernel(const HistArgs a)
+{
+    const int s = blockIdx.x, c = threadIdx.x, NH = a.n_heights, W = 24 + 3 + NH;
+    if (s >= a.n_seq || c >= W) return;
+    const int H = a.history, T = a.n_steps, n = T < H ? T : H;
+    float* col;
+    int stride;
+    if (c < 24) { col = a.latent_buf + (size_t)s * H * 24 + c; stride = 24; }
+    else if (c < 27) { col = a.disp_buf + (size_t)s * H * 3 + (c - 24); stride = 3; }
+    else { col = a.heights_buf + (size_t)s * H * NH + (c - 27); stride = NH; }
+    for (int t = 0; t < H; ++t)
+        col[(size_t)t * stride] = t + n < H ? col[(size_t)(t + n) * stride] : a.scratch[((size_t)(T - H + t) * a.n_seq + s) * W + c];
+}
+
+extern "C" hipError_t dp_launch_sequence_history(const HistArgs* args, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dp_sequence_history_kernel, dim3(args->n_seq), dim3(64), 0, stream, *args);
+    return hipGetLastError();
+}

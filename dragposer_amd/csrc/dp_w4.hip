@@ -48,7 +48,13 @@ constexpr int FB_ZT = FB_ZPRE + LAT;         // [24] z_tgt (epilogue only)
 constexpr int FB_LT = FB_ZT + LAT;           // [24] early stop: (z - z_tgt)^2 per latent dim of the current latent
 constexpr int FB_ES = FB_LT + LAT;           // [4]  early stop: losses of the frame's last executed iteration (pos, rot, tmp, -)
 constexpr int FB_CUR = FB_ES + 4;            // [4]  cur_rot of the frame (for the epilogue)
-constexpr int FB_END = FB_CUR + 4;
+// whole-sequence launches (SeqK): what the per-step state update reads from the epilogue's lanes, and the running state
+constexpr int FB_GPOS = FB_CUR + 4;          // [4]  current global position of the sequence
+constexpr int FB_SWD = FB_GPOS + 4;          // [4]  this step's world displacement
+constexpr int FB_SD = FB_SWD + 4;            // [4]  this step's root-space displacement
+constexpr int FB_SQW = FB_SD + 4;            // [4]  this step's world rotation
+constexpr int FB_SPOS = FB_SQW + 4;          // [22][3] this step's joint positions (+ 2 pad)
+constexpr int FB_END = FB_SPOS + 68;
 constexpr int QS_DISP = ITEM_DISP, QS_IDENT = 30, QS_TRASH = 31, WT_ZERO = 30, WT_TRASH = 31;
 // the four frames of a wave sit in the four lanes of every quad: block stride = 16 banks (mod 64) apart, so that the
 // quad's 16-byte accesses to the same row of four blocks never share a bank
@@ -297,8 +303,9 @@ struct TRaw {
     unsigned plo, phi;
     float p[3], wp, wr, m[9];
 };
-DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, int E, int rank)
+DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, int E, int rank, int gf_tgt = -1)
 { // (!optimise: no tracker arrays -- E = 0, every lane inactive; the loads read the weight image instead and are ignored)
+  // gf_tgt: row of the targets when it differs from the row of the weights (whole-sequence launches: step * S + sequence)
     TRaw r;
     r.act = rank < E;
     r.rank = rank;
@@ -307,8 +314,9 @@ DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, in
     r.plo = a.items[j].path_lo;
     r.phi = a.items[j].path_hi;
     const int row = optimise ? gf * NJ + j : 0; // (inactive lanes read joint 0's inputs and ignore them)
-    const float* p = (optimise ? a.tgt_pos : a.w4img) + (size_t)row * 3;
-    const float* rm = (optimise ? a.tgt_rot : a.w4img) + (size_t)row * 9;
+    const size_t rowt = optimise ? (size_t)(gf_tgt >= 0 ? gf_tgt : gf) * NJ + j : 0;
+    const float* p = (optimise ? a.tgt_pos : a.w4img) + rowt * 3;
+    const float* rm = (optimise ? a.tgt_rot : a.w4img) + rowt * 9;
     const float* wv = (optimise ? a.w : a.w4img) + (size_t)row * 2;
     r.p[0] = p[0]; r.p[1] = p[1]; r.p[2] = p[2];
     r.wp = wv[0];
@@ -317,8 +325,8 @@ DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, in
     for (int k = 0; k < 9; ++k) r.m[k] = rm[k];
     return r;
 }
-DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur)
-{
+DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur, V3 shift = V3{0.f, 0.f, 0.f})
+{ // shift: added to the position target (whole-sequence launches: tgt_root[t] - current global position)
     TRec t;
     t.act = r.act;
     t.rank = r.rank;
@@ -332,7 +340,7 @@ DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur)
     t.cgp = t.clp = t.k8 = t.clr8 = 0.f;
     if (t.act) {
         const float invE = 1.f / (float)E;
-        t.tp = rot_conj(cur, V3{r.p[0], r.p[1], r.p[2]});
+        t.tp = rot_conj(cur, V3{r.p[0] + shift.x, r.p[1] + shift.y, r.p[2] + shift.z});
         const Q4 qT = quat_mul(Q4{cur.w, -cur.x, -cur.y, -cur.z}, quat_from_rotmat(r.m));
         t.qT0 = f2{qT.w, qT.x}; t.qT1 = f2{qT.y, qT.z};
         t.clp = r.wp * invE * (1.f / 3.f);                       // loss_pos coefficient  w_pos / (3E)
@@ -347,9 +355,9 @@ DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur)
     }
     return t;
 }
-DEV TRec make_tracker(const KArgs& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur)
+DEV TRec make_tracker(const KArgs& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur, int gf_tgt = -1, V3 shift = V3{0.f, 0.f, 0.f})
 {
-    return tracker_finish(a, fb, tracker_fetch(a, true, gf, tmask, E, rank), E, cur);
+    return tracker_finish(a, fb, tracker_fetch(a, true, gf, tmask, E, rank, gf_tgt), E, cur, shift);
 }
 
 DEV TRec load_tracker(const KArgs& a, const float* fb, int E, int rank)
@@ -546,8 +554,10 @@ DEV void out_consts(const float* oc, int itemA, int kindA, int itemB, int kindB,
     oA.plo = __float_as_uint(pw.x); oA.phi = __float_as_uint(pw.y);
     oB.plo = __float_as_uint(pw.z); oB.phi = __float_as_uint(pw.w);
 }
-DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
-{
+template <bool SEQ = false>
+DEV void w4_outputs(const KArgs& a, const OutC& oc, float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
+{ // SEQ (whole-sequence launches): gf = step * S + sequence; the state update's inputs are also left in the frame block, and the
+  // pose written is the one run() RETURNS (root channels = the normalised world rotation, drag_pose.py:394-396)
     const int item = oc.item, kind = oc.kind;
     if (item < 0 || kind == KIND_IDLE || kind == KIND_VIRT) return;
     const f4 sd = oc.sd, mu = oc.mu;
@@ -558,18 +568,24 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, boo
     const M3 R0 = quat_to_mat(qw);
     if (kind == KIND_DISP) {
         if (a.disp) { float* o = a.disp + (size_t)gf * 3; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; }
-        if (a.world_disp) {
+        if (a.world_disp || SEQ) {
             const V3 wd = mat_vec(R0, V3{rq.w, rq.x, rq.y});
-            float* o = a.world_disp + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z;
+            if (a.world_disp) { float* o = a.world_disp + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z; }
+            if (SEQ) { *(f4*)(fb + FB_SWD) = f4{wd.x, wd.y, wd.z, 0.f}; *(f4*)(fb + FB_SD) = f4{rq.w, rq.x, rq.y, 0.f}; }
         }
         return;
     }
     const Q4 q = rq;
     if (a.pose) {
         float* o = a.pose + (size_t)gf * 88 + 4 * item;
-        o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y; o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+        if (SEQ && kind == KIND_ROOT) {
+            o[0] = (qw.w - a.seq.mean_q0[0]) / a.seq.std_q0[0]; o[1] = (qw.x - a.seq.mean_q0[1]) / a.seq.std_q0[1];
+            o[2] = (qw.y - a.seq.mean_q0[2]) / a.seq.std_q0[2]; o[3] = (qw.z - a.seq.mean_q0[3]) / a.seq.std_q0[3];
+        } else {
+            o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y; o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+        }
     }
-    if (a.pos) {
+    if (a.pos || SEQ) {
         const f4 dv = *(const f4*)(fb + FB_QS + 4 * QS_DISP);
         V3 pr = {dv.x, dv.y, dv.z};
         const unsigned plo = oc.plo, phi = oc.phi;
@@ -579,8 +595,8 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, boo
 #pragma unroll
         for (int k = 0; k < MAX_PATH; ++k) { pr.x += bn[k].x; pr.y += bn[k].y; pr.z += bn[k].z; }
         const V3 pw = mat_vec(R0, pr);
-        float* o = a.pos + ((size_t)gf * NJ + item) * 3;
-        o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+        if (a.pos) { float* o = a.pos + ((size_t)gf * NJ + item) * 3; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
+        if (SEQ) { float* o = fb + FB_SPOS + 3 * item; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
     }
     if (a.rot) {
         M3 M = quat_to_mat(q);
@@ -591,6 +607,7 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, boo
     }
     if (kind == KIND_ROOT) {
         if (a.world_rot) { float* o = a.world_rot + (size_t)gf * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
+        if (SEQ) *(f4*)(fb + FB_SQW) = f4{qw.w, qw.x, qw.y, qw.z};
         if (optimise && a.loss && early) { // losses of the frame's last executed iteration, as the stop test saw them
             const f4 es = *(const f4*)(fb + FB_ES);
             a.loss[(size_t)gf * 3 + 0] = es.x; a.loss[(size_t)gf * 3 + 1] = es.y; a.loss[(size_t)gf * 3 + 2] = es.z;
@@ -623,9 +640,13 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, const float* fb, int gf, boo
 #ifndef W4_B2_RES_V
 #define W4_B2_RES_V 2
 #endif
-template <int NW, bool EARLY>
+// SEQ (whole-sequence launches, dp_optimize_sequence): frames are SEQUENCES; the kernel loops over a.seq.n_steps frame indices,
+// carrying every sequence's state (latent, global position / rotation) from step to step in registers and LDS -- the per-frame
+// epilogue of drag_pose.py:369-402 included -- and writes each step's results to the step's slab of the output arrays.
+template <int NW, bool EARLY, bool SEQ = false>
 __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 {
+    static_assert(!SEQ || EARLY, "sequences run the reference's while-condition");
     __shared__ __attribute__((aligned(16))) float lds[lds_total<NW>()];
 
 #ifdef DP_PROFILE
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         for (int r = 0; r < FPW; ++r) {
             const int gf = min(f0 + r, nB - 1);
             zD[r] = a.z0[(size_t)gf * LAT + lane];
-            if (optimise) ztD[r] = a.z_tgt[(size_t)gf * LAT + lane];
+            if (optimise) ztD[r] = a.z_tgt[(size_t)gf * (SEQ ? a.seq.z_tgt_seq : LAT) + lane];
         }
     }
     // kinematics constants of my quad's two items
@@ -804,8 +825,15 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     TRec trk;
     {
         const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
-        trk = tracker_finish(a, fb, raw, E, cur);
-        for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur); // (uniform, rare)
+        V3 shift = {0.f, 0.f, 0.f};
+        if (SEQ) {
+            const float* gpp = a.seq.global_pos + (size_t)gfi * 3;
+            const V3 gp0 = {gpp[0], gpp[1], gpp[2]};
+            if (a.seq.tgt_root) { const float* rp = a.seq.tgt_root + (size_t)gfi * 3; shift = {rp[0] - gp0.x, rp[1] - gp0.y, rp[2] - gp0.z}; }
+            if (b == 0) *(f4*)(fb + FB_GPOS) = f4{gp0.x, gp0.y, gp0.z, 0.f};
+        }
+        trk = tracker_finish(a, fb, raw, E, cur, shift);
+        for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur, -1, shift); // (uniform, rare)
     }
     if (b == 0) *(f4*)(fb + FB_QS + 4 * QS_IDENT) = f4{1.f, 0.f, 0.f, 0.f};
     if (b < MAX_ROOT_CH) *(f4*)(fb + FB_BN + 4 * init_id) = init_off;
@@ -839,6 +867,46 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.t[15] = prof.prev - t_setup[2];  // resident weights arrived
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;
 #endif
+    // SEQ: the argument block re-read from the kernarg segment per step through an opaque pointer, so that its fields (some 140
+    // scalar registers' worth) are loaded where a step uses them instead of being held -- and spilled -- across the iteration loop
+    auto step_args = [&]() -> const KArgs& {
+        if (!SEQ) return a;
+        const KArgs* p = (const KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
+    int step = 0;
+    do { // (one pass unless SEQ)
+    if (SEQ) {
+        const KArgs& as = step_args();
+        V3 step_shift = {0.f, 0.f, 0.f};
+        int gft = step * nB + gfi;
+        asm volatile("" : "+v"(gft)); // (opaque: keeps this step's address arithmetic out of the registers live across the iteration loop)
+        if (as.seq.tgt_root) {
+            const float* rp = as.seq.tgt_root + (size_t)gft * 3;
+            const f4 gpv = *(const f4*)(fb + FB_GPOS);
+            step_shift = {rp[0] - gpv.x, rp[1] - gpv.y, rp[2] - gpv.z};
+        }
+        if (step > 0) { // the next frame of every sequence: its targets, a warm-started latent, a fresh Adam state (drag_pose.py:218)
+            const f4 cvs = *(const f4*)(fb + FB_CUR);
+            const Q4 cur = {cvs.x, cvs.y, cvs.z, cvs.w};
+            trk = tracker_finish(as, fb, tracker_fetch(as, true, gfi, tmask, E, b, gft), E, cur, step_shift);
+            for (int base = 16; base < Emax; base += 16) make_tracker(as, fb, gfi, tmask, E, base + b, cur, gft, step_shift); // (uniform, rare)
+            zD = zfinD;
+            mD = f4{0.f, 0.f, 0.f, 0.f}; vD = mD;
+            if (lane < LAT) {
+#pragma unroll
+                for (int r = 0; r < FPW; ++r) {
+                    const int gf = min(f0 + r, nB - 1);
+                    ztD[r] = as.z_tgt[(size_t)step * as.seq.z_tgt_step + (size_t)gf * as.seq.z_tgt_seq + lane];
+                    const float dz = zD[r] - ztD[r];
+                    fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz;
+                }
+            }
+            es_prev = 10000000.f; es_act = true; es_iters = 0;
+            wave_sync();
+        }
+    }
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
         const f2 adam_t = *(const f2*)(lds + L_TAB + 2 * iter); // (an LDS broadcast read, issued a whole iteration ahead of its use)
@@ -1019,6 +1087,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #endif
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
+    const KArgs& ae = step_args();
+    int row0 = SEQ ? step * nB : 0; // SEQ: this step's slab of the per-step output arrays
+    int gfo = row0 + gfi;
+    if (SEQ) { asm volatile("" : "+v"(gfo)); asm volatile("" : "+s"(row0)); } // (opaque, as above)
     if (lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
@@ -1031,22 +1103,60 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         const f4 cve = *(const f4*)(fb + FB_CUR);
         OutC oA, oB;
         out_consts(lds + L_OC + 20 * b, pc.itemA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, pc.itemB, pc.kindB, oA, oB);
-        if (fvalid) {
+        if (fvalid || SEQ) { // (SEQ: the clamped copies of a ragged tail keep their own state consistent; their stores are skipped below)
             const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
-            w4_outputs(a, oA, fb, gfi, optimise, cur, tmask, EARLY);
-            w4_outputs(a, oB, fb, gfi, optimise, cur, tmask, EARLY);
+            if (!SEQ || fvalid) {
+                w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY);
+                w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY);
+            }
         }
     }
     if (optimise && lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
             if (f0 + r < nB) {
-                if (a.z) a.z[(size_t)(f0 + r) * LAT + lane] = EARLY ? zfinD[r] : zD[r];
-                if (a.z_pre) a.z_pre[(size_t)(f0 + r) * LAT + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
+                if (ae.z && (!SEQ || step == ae.seq.n_steps - 1)) ae.z[(size_t)(f0 + r) * LAT + lane] = EARLY ? zfinD[r] : zD[r];
+                if (ae.z_pre) ae.z_pre[(size_t)(row0 + f0 + r) * LAT + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
+                if (SEQ) ae.seq.hist[(size_t)(row0 + f0 + r) * (LAT + 3 + ae.seq.n_heights) + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
             }
         }
     }
-    if (optimise && a.iters && lane < FPW && f0 + lane < nB) a.iters[f0 + lane] = EARLY ? es_iters : a.n_iter;
+    if (optimise && ae.iters && lane < FPW && f0 + lane < nB) ae.iters[row0 + f0 + lane] = EARLY ? es_iters : ae.n_iter;
+    if (SEQ) { // the rest of run()'s epilogue (drag_pose.py:369-391), one lane per sequence: dp_sequence_advance's arithmetic
+        wave_sync();
+        if (b == 0 && fvalid) {
+            const f4 wd = *(const f4*)(fb + FB_SWD), qw = *(const f4*)(fb + FB_SQW), gp0 = *(const f4*)(fb + FB_GPOS);
+            f4 ds = *(const f4*)(fb + FB_SD);
+            float gp[3] = {gp0.x + wd.x, gp0.y + wd.y, gp0.z + wd.z}; // drag_pose.py:370
+            float dsp[3] = {ds.x, ds.y, ds.z};
+            if (ae.seq.adjust_joint >= 0) { // drag_pose.py:374-381
+                const float* tpp = ae.tgt_pos + ((size_t)gfo * NJ + ae.seq.adjust_target_joint) * 3;
+                float sh[3] = {0.f, 0.f, 0.f}; // this step's target shift again (tgt_root[t] - the global position BEFORE this step)
+                if (ae.seq.tgt_root) { const float* rp = ae.seq.tgt_root + (size_t)gfo * 3; sh[0] = rp[0] - gp0.x; sh[1] = rp[1] - gp0.y; sh[2] = rp[2] - gp0.z; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float adj = ((tpp[k] + sh[k]) - fb[FB_SPOS + 3 * ae.seq.adjust_joint + k]) * ae.seq.adjust_weight;
+                    gp[k] += adj;
+                    dsp[k] += adj;
+                }
+            }
+            if (ae.seq.pos_ret) { float* o = ae.seq.pos_ret + (size_t)gfo * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; }
+            {
+                float* o = ae.seq.hist + (size_t)gfo * (LAT + 3 + ae.seq.n_heights) + LAT;
+                o[0] = dsp[0]; o[1] = dsp[1]; o[2] = dsp[2];
+                for (int h = 0; h < ae.seq.n_heights; ++h) o[3 + h] = fb[FB_SPOS + 3 * ae.seq.height_joints[h] + 1] + gp[1];
+            }
+            *(f4*)(fb + FB_GPOS) = f4{gp[0], gp[1], gp[2], 0.f};
+            *(f4*)(fb + FB_CUR) = qw; // drag_pose.py:371
+            if (step == ae.seq.n_steps - 1) {
+                float* o = ae.seq.global_pos + (size_t)gfi * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
+                *(f4*)(ae.seq.global_rot + (size_t)gfi * 4) = qw;
+            }
+        }
+        wave_sync();
+    }
+    ++step;
+    } while (SEQ && step < a.seq.n_steps);
 #ifdef DP_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the epilogue's stores have left the wave
     STAMP(11);
@@ -1058,7 +1168,9 @@ extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream)
 {
     constexpr int NW = 4;
     const int grid = (args->n_frames + NW * FPW - 1) / (NW * FPW);
-    if (args->early_stop && args->mode == 0)
+    if (args->seq.n_steps > 0)
+        hipLaunchKernelGGL((dp_w4_kernel<NW, true, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    else if (args->early_stop && args->mode == 0)
         hipLaunchKernelGGL((dp_w4_kernel<NW, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
     else
         hipLaunchKernelGGL((dp_w4_kernel<NW, false>), dim3(grid), dim3(NW * 64), 0, stream, *args);

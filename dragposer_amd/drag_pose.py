@@ -189,6 +189,56 @@ class DragPose:
                                         tgt_rot=torch.zeros(S, NJ, 9, device=dev))
         return self._trk_cache[key]
 
+    def run_frames(self, target_ee_pos, target_ee_rot, mask_joints, weights_joints, target_root=None, stop_eps_pos=1e-2, stop_eps_rot=1e-2,
+                   max_iter=100, min_loss_incr=0.00001, learning_rate=1e-3, lambda_rot=1, lambda_temporal=1, temporal_future_window=60,
+                   height_indices=(0, 4, 8, 13, 17, 21), joint_adjustment_indices=None, joint_adjustment_weight=0.01):
+        """T consecutive frames of every sequence -- T calls of run() -- with the frame loop on the device: one kernel launch per
+        stretch of frames between two temporal predictions (all T of them when there is no predictor or lambda_temporal is 0).
+        target_ee_pos [T,S,E,3], target_ee_rot [T,S,E,3,3]; `target_root` [T,S,3] or None: given, the position targets of frame t
+        are target_ee_pos[t] + (target_root[t] - current_global_pos) as eval_drag builds them (eval_drag.py:186-199), which no
+        caller can do ahead of time.  Returns (poses [T,S,88], global positions [T,S,3], iterations [T,S])."""
+        dev, S = self.device, self.S
+        tp = torch.as_tensor(target_ee_pos, dtype=torch.float32, device=dev)
+        T = int(tp.shape[0])
+        tp = tp.reshape(T, S, -1, 3)
+        tR = torch.as_tensor(target_ee_rot, dtype=torch.float32, device=dev).reshape(T, S, -1, 9)
+        trk = self._trackers(mask_joints, weights_joints)
+        E = trk["mj"].numel()
+        if tp.shape[2] != E or tR.shape[2] != E:
+            raise ValueError("target_ee_pos / target_ee_rot / weights_joints must have one row per entry of mask_joints")
+        dense_p = torch.zeros(T, S, NJ, 3, device=dev)
+        dense_r = torch.zeros(T, S, NJ, 9, device=dev)
+        dense_p.index_copy_(2, trk["mj"], tp)
+        dense_r.index_copy_(2, trk["mj"], tR)
+        root = torch.as_tensor(target_root, dtype=torch.float32, device=dev).reshape(T, S, 3).contiguous() if target_root is not None else None
+        adjust = None
+        if joint_adjustment_indices is not None:
+            joint_index, ee_index = joint_adjustment_indices
+            adjust = (int(joint_index), int(trk["mj_host"][ee_index]), float(joint_adjustment_weight))
+        poses = torch.empty(T, S, 88, device=dev)
+        gpos = torch.empty(T, S, 3, device=dev)
+        iters = torch.empty(T, S, dtype=torch.int32, device=dev)
+        pull = self.temporal is not None and float(lambda_temporal) != 0.0
+        window = int(temporal_future_window)
+        zero_tgt = torch.zeros(S, LATENT, device=dev)
+        t = 0
+        while t < T:
+            if pull:  # frames up to the next prediction (a prediction every `window` frames; every frame when window = 0)
+                self._temporal_targets(window)
+                n = min(T - t, max(window, 1) - self.current_index)
+                z_tgt, strides = self.target_latent_buffer[:, self.current_index:], (LATENT, (window + 1) * LATENT)
+            else:
+                n, z_tgt, strides = T - t, zero_tgt, (0, LATENT)
+            self.opt.optimize_sequence(self.latent, dense_p[t:t + n], dense_r[t:t + n], root[t:t + n] if root is not None else None,
+                                       trk["w"], trk["tracked"], z_tgt, strides, self.current_global_pos, self.current_global_rot,
+                                       self.latent_buffer, self.displacement_buffer, self.heights_buffer, tuple(int(h) for h in height_indices),
+                                       n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot), lambda_tmp=float(lambda_temporal) if pull else 0.0,
+                                       stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot, min_loss_incr=min_loss_incr, adjust=adjust,
+                                       pose_ret=poses[t:t + n], pos_ret=gpos[t:t + n], iters=iters[t:t + n])
+            t += n
+            self.current_index = 0 if window == 0 else (self.current_index + n) % window
+        return poses, gpos, iters
+
     def run(self, target_ee_pos, target_ee_rot, mask_joints, weights_joints, offsets=None, stop_eps_pos=1e-2,
             stop_eps_rot=1e-2, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-3, lambda_rot=1, lambda_temporal=1,
             temporal_future_window=60, height_indices=(0, 4, 8, 13, 17, 21), joint_adjustment_indices=None,

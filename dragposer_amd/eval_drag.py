@@ -115,7 +115,14 @@ def run_sequences(args, seqs, opt, temporal_pack, cfg):
     iters = torch.zeros(T, S, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     t0 = time.time()
-    for i in range(T):
+    if not getattr(args, "per_frame", False):
+        # the frame loop on the device: one launch per stretch of frames between two temporal predictions (DragPose.run_frames)
+        print(f"Frames: {T} (frame loop on the device)", flush=True)
+        poses, out_pos, iters = drag.run_frames(tp_rel, tR.reshape(T, S, -1, 3, 3), mask_idx, weights, target_root=gpos, stop_eps_pos=0.01 * 0.01,
+                                                stop_eps_rot=0.01, max_iter=args.max_iter, min_loss_incr=0.00001, learning_rate=1e-2, lambda_rot=1,
+                                                lambda_temporal=lam_tmp, temporal_future_window=window, height_indices=HEIGHT_INDICES,
+                                                joint_adjustment_indices=ja, joint_adjustment_weight=cfg["joint_adjustment_weight"])
+    for i in range(T if getattr(args, "per_frame", False) else 0):
         if i % 1000 == 0:
             print(f"Frame: {i + 1} out of {T}", flush=True)
         tp = tp_rel[i] + (gpos[i] - drag.current_global_pos).unsqueeze(1)  # eval_drag.py:186-199
@@ -176,6 +183,9 @@ def main(argv=None):
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--out-dir", default="data")
+    ap.add_argument("--per-frame", action="store_true",
+                    help="drive the frame loop from the host, one DragPose.run (two launches) per frame, as the reference does (default: the "
+                         "frame loop runs on the device, DragPose.run_frames; same results)")
     ap.add_argument("--lockstep", action="store_true",
                     help="directory input: advance all files together, one kernel launch per frame index for all of them "
                          "(same per-file results; the reference evaluates them one after the other)")

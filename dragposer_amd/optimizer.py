@@ -191,6 +191,65 @@ class LatentOptimizer:
             self._fail(rc)
 
 
+def _optimize_sequence(self, latent, tgt_pos, tgt_rot, tgt_root, w, tracked, z_tgt, z_tgt_strides, global_pos, global_rot, latent_buf, disp_buf,
+                       heights_buf, height_joints, n_iter=100, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, lambda_rot=1.0, lambda_tmp=0.0,
+                       stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5, adjust=None, pose_ret=None, pos_ret=None, iters=None,
+                       loss=None, scratch=None):
+    """T consecutive frames of S sequences in one launch (include/dragposer.h: dp_optimize_sequence): the optimise loop with the
+    reference's while-condition and run()'s epilogue per frame, state carried on the device.  tgt_pos [T,S,22,3] / tgt_rot
+    [T,S,22,9] dense per joint; tgt_root [T,S,3] or None (position targets are then tgt_pos + (tgt_root[t] - running global
+    position), eval_drag.py:186-199); w [S,22,2], tracked [S,22]; z_tgt any fp32 device tensor addressed with `z_tgt_strides` =
+    (floats between steps, floats between sequences).  `latent` [S,24], `global_pos`, `global_rot` and the three history
+    buffers are updated IN PLACE.  Returns dict(pose_ret [T,S,88], pos_ret [T,S,3], iters [T,S], loss [T,S,3])."""
+    T, S = int(tgt_pos.shape[0]), int(tgt_pos.shape[1])
+    dev = self.device
+    H, NH = int(latent_buf.shape[1]), len(height_joints)
+    fr = _lib.DpSeqFrames()
+    fr.n_steps = T
+    fr.tgt_pos = _check(tgt_pos, "tgt_pos", (T, S, NJ, 3), torch.float32, dev)
+    fr.tgt_rot = _check(tgt_rot, "tgt_rot", (T, S, NJ, 9), torch.float32, dev)
+    fr.tgt_root = _check(tgt_root, "tgt_root", (T, S, 3), torch.float32, dev) if tgt_root is not None else None
+    fr.w = _check(w, "w", (S, NJ, 2), torch.float32, dev)
+    fr.tracked = _check(tracked, "tracked", (S, NJ), torch.uint8, dev)
+    if z_tgt.device != dev or z_tgt.dtype != torch.float32:
+        raise ValueError("z_tgt: expected an fp32 tensor on the optimiser's device")
+    fr.z_tgt, fr.z_tgt_step, fr.z_tgt_seq = z_tgt.data_ptr(), int(z_tgt_strides[0]), int(z_tgt_strides[1])
+    st = _lib.DpSeqState()
+    st.global_pos = _check(global_pos, "global_pos", (S, 3), torch.float32, dev)
+    st.global_rot = _check(global_rot, "global_rot", (S, 4), torch.float32, dev)
+    st.latent_buf = _check(latent_buf, "latent_buf", (S, H, LATENT), torch.float32, dev)
+    st.disp_buf = _check(disp_buf, "disp_buf", (S, H, 3), torch.float32, dev)
+    st.heights_buf = _check(heights_buf, "heights_buf", (S, H, NH), torch.float32, dev)
+    st.history, st.n_heights = H, NH
+    for i, j in enumerate(height_joints):
+        st.height_joints[i] = int(j)
+    step = _lib.DpSeqStep()
+    step.adjust_joint = -1
+    if adjust is not None:
+        step.adjust_joint, step.adjust_target_joint, step.adjust_weight = int(adjust[0]), int(adjust[1]), float(adjust[2])
+    res = _lib.DpSeqResults()
+    outs = {}
+    for name, t, shape, dtype in (("pose_ret", pose_ret, (T, S, 88), torch.float32), ("pos_ret", pos_ret, (T, S, 3), torch.float32),
+                                  ("iters", iters, (T, S), torch.int32), ("loss", loss, (T, S, 3), torch.float32)):
+        t = t if t is not None else torch.empty(shape, dtype=dtype, device=dev)
+        setattr(res, name, _check(t, name, shape, dtype, dev))
+        outs[name] = t
+    scratch = scratch if scratch is not None else torch.empty(T, S, LATENT + 3 + NH, device=dev)
+    res.hist_scratch = _check(scratch, "scratch", (T, S, LATENT + 3 + NH), torch.float32, dev)
+    p = _lib.DpParams(n_iter=int(n_iter), lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, lambda_rot=lambda_rot, lambda_tmp=lambda_tmp,
+                      early_stop=1, stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
+                      min_loss_incr=float("-inf") if min_loss_incr is None else min_loss_incr, max_trackers=0, kernel=_lib.DP_KERNEL_AUTO)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = self.lib.dp_optimize_sequence(self.ctx, S, C.c_void_p(_check(latent, "latent", (S, LATENT), torch.float32, dev)), C.byref(fr),
+                                       C.byref(p), C.byref(st), C.byref(step), C.byref(res), stream)
+    if rc != _lib.DP_OK:
+        self._fail(rc)
+    return outs
+
+
+LatentOptimizer.optimize_sequence = _optimize_sequence
+
+
 def check_rotation_targets(tgt_rot, tracked, tol=1e-3):
     """Raises ValueError unless every tracked joint's 3x3 target is orthonormal with determinant +1 (within `tol`)."""
     R = tgt_rot.reshape(-1, NJ, 3, 3)

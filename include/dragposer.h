@@ -190,6 +190,40 @@ typedef struct dp_seq_step {
 int dp_sequence_advance(dp_ctx* ctx, int n_sequences, const dp_result* res, const dp_seq_state* state, const dp_seq_step* step,
                         void* hip_stream);
 
+/* ---- whole-sequence launches ------------------------------------------------------------------------------------------
+ * n_steps consecutive frames of S sequences in ONE launch: per step the optimise loop with the reference's while-condition
+ * (dp_params.early_stop is implied), then run()'s epilogue (what dp_sequence_advance does), the state carried from step to step
+ * on the device.  The caller knows the targets of all steps up front (eval_drag.py:164-222 builds them from the ground-truth
+ * file); what it cannot know is the running global position they are relative to -- hence tgt_root.  A second, tiny launch
+ * appends the steps to the three history buffers.  The temporal predictor is not part of it: callers with a predictor cut the
+ * sequence at the frames where it is due (every `window` frames) and call dp_temporal_predict in between. */
+typedef struct dp_seq_frames {   /* DEVICE pointers; T = n_steps */
+    int n_steps;
+    const float* tgt_pos;  /* [T][S][22][3] position targets (see tgt_root) */
+    const float* tgt_rot;  /* [T][S][22][9] rotation targets */
+    const float* tgt_root; /* [T][S][3] or NULL.  Given: the position targets of step t are tgt_pos[t] + (tgt_root[t] - the
+                              sequence's global position before step t), i.e. tgt_pos holds root-relative positions and tgt_root
+                              the target root trajectory (eval_drag.py:186-199); NULL: tgt_pos is used as it is */
+    const float* w;        /* [S][22][2] tracker weights, the same for every step */
+    const unsigned char* tracked; /* [S][22] */
+    const float* z_tgt;    /* temporal targets: element k of sequence s at step t = z_tgt[t * z_tgt_step + s * z_tgt_seq + k] */
+    int z_tgt_step, z_tgt_seq; /* (one row held for all steps: z_tgt_step = 0; rows of a [S][window + 1][24] target buffer: 24, (window + 1) * 24) */
+} dp_seq_frames;
+
+typedef struct dp_seq_results {  /* DEVICE pointers, per step; any but hist_scratch may be NULL */
+    float* pose_ret;     /* [T][S][88] what run() returns (root channels = the normalised world rotation) */
+    float* pos_ret;      /* [T][S][3]  returned global position */
+    int* iters;          /* [T][S]     iterations executed */
+    float* loss;         /* [T][S][3]  losses of the frame's last executed iteration */
+    float* hist_scratch; /* [T][S][24 + 3 + NH] floats of caller-owned scratch (the steps' history rows before they are appended) */
+} dp_seq_results;
+
+/* latent [S][24]: in = the warm start of the first step, out = the latent after the last.  state: global_pos / global_rot
+ * in and out, the three history buffers advanced by n_steps.  adjust: the joint-adjustment fields of dp_seq_step (its pointers
+ * are ignored).  Asynchronous on the stream, no allocation. */
+int dp_optimize_sequence(dp_ctx* ctx, int n_sequences, float* latent, const dp_seq_frames* frames, const dp_params* params,
+                         const dp_seq_state* state, const dp_seq_step* adjust, const dp_seq_results* out, void* hip_stream);
+
 /* ---- temporal predictor (reference: Temporal, temporal_transformer.py:7-77, positional_encoding.py:6-32; its use in
  * DragPose.run, drag_pose.py:234-294) -----------------------------------------------------------------------------
  * The Transformer that predicts the latents of the next frames from the 60-frame history; its output is `z_tgt`, the

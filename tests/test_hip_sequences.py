@@ -163,6 +163,41 @@ def test_eval_drag_cli_on_bvh_clip(tmp_path):
     assert res["mean_iters"] < 60
 
 
+@pytest.mark.parametrize("name", ["seq6", "seq3", "sequ"])
+def test_frame_loop_on_the_device_equals_per_frame_calls(golden_dir, name):
+    """DragPose.run_frames (dp_optimize_sequence: the frame loop inside one launch per stretch between two temporal predictions)
+    against T calls of DragPose.run, on the reference-recorded sequences with their temporal predictor and joint adjustment:
+    every returned pose, global position, iteration count and the whole state afterwards, BIT FOR BIT."""
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    g = R.load_golden(os.path.join(golden_dir, f"{name}.npz"))
+    mt, cfg = g["meta"], g["meta"]["cfg"]
+    K, T = mt["K"], mt["T"]
+    opt = LatentOptimizer(device="cuda:0")
+    ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
+    kw = dict(stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-2, lambda_rot=1,
+              lambda_temporal=cfg["lambda_temporal"], temporal_future_window=cfg["temporal_future_window"], joint_adjustment_indices=ja,
+              joint_adjustment_weight=cfg["joint_adjustment_weight"])
+    dps = []
+    for _ in range(2):
+        dp = DragPose(opt, _load_temporal(g), g["means_latent"], g["stds_latent"], n_sequences=K, native_temporal=True)
+        dp.set_initial_state(g["z0"], np.zeros((K, 3), np.float32), g["init_rot"], g["init_heights"])
+        dps.append(dp)
+    a, b = dps
+    pa, ga, ia = [], [], []
+    for t in range(T):
+        pose, gpos = a.run(g["tgt_pos"][t].reshape(K, -1, 3), g["tgt_rot"][t].reshape(K, -1, 9), g["mask_idx"], g["weights"], **kw)
+        pa.append(pose.reshape(K, 88).clone()); ga.append(gpos.reshape(K, 3).clone()); ia.append(a.last["iters"].clone())
+    pb, gb, ib = b.run_frames(g["tgt_pos"].reshape(T, K, -1, 3), g["tgt_rot"].reshape(T, K, -1, 3, 3), g["mask_idx"], g["weights"], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(ia), ib) and torch.equal(torch.stack(pa), pb) and torch.equal(torch.stack(ga), gb)
+    for attr in ("latent", "current_global_pos", "current_global_rot", "latent_buffer", "displacement_buffer", "heights_buffer"):
+        assert torch.equal(getattr(a, attr), getattr(b, attr)), attr
+    assert a.current_index == b.current_index
+    assert int(ib.max()) >= 50 and int(ib.min()) <= 3  # both exits of the while-condition occur
+
+
 def test_config1_full_example(tmp_path):
     """BASELINE config 1 at full size: eval_drag on data/example/eval/example.bvh (5052 frames, 120 Hz), 6-tracker config,
     the reference's early-stop settings (eval_drag.py:210-214), one sequential sequence.  The clip is data of the reference,
@@ -177,11 +212,15 @@ def test_config1_full_example(tmp_path):
     path = os.path.join(root, "tests", "data", "_local", "example.bvh")
     if not os.path.exists(path):
         pytest.skip("example.bvh not staged (build() copies it where /root/reference is mounted)")
+    cfg6 = os.path.join(root, "dragposer_amd", "config", "6_trackers_config.json")
+    per = eval_drag.main([path, "--config", cfg6, "--out-dir", str(tmp_path / "per_frame"), "--per-frame"])[0]  # the host drives every frame
     t0 = time.time()
-    res = eval_drag.main([path, "--config", os.path.join(root, "dragposer_amd", "config", "6_trackers_config.json"), "--out-dir", str(tmp_path)])[0]
+    res = eval_drag.main([path, "--config", cfg6, "--out-dir", str(tmp_path)])[0]  # default: the frame loop on the device, one launch
     wall = time.time() - t0
     print(f"config 1: {res['frames']} frames, MPJPE {res['mpjpe'] * 1000:.1f} mm, MPEEPE {res['mpeepe'] * 1000:.1f} mm, frame loop {res['time']:.3f} s "
-          f"({res['frames'] / res['time']:.0f} frames/s, {res['mean_iters']:.1f} iterations/frame), whole CLI {wall:.1f} s")
+          f"({res['frames'] / res['time']:.0f} frames/s, {res['mean_iters']:.1f} iterations/frame; host-driven loop {per['time']:.3f} s), whole CLI {wall:.1f} s")
+    assert open(res["out"], "rb").read() == open(per["out"], "rb").read()  # the same result file, byte for byte
+    assert res["time"] < 0.25
     assert res["frames"] == 5052 and os.path.exists(res["out"])
     assert res["mpjpe"] < 0.035 and res["mpeepe"] < 0.040, res  # metres
     assert res["mean_iters"] < 30
