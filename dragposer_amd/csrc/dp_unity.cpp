@@ -421,6 +421,8 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     const bool have_predictor = d->temporal != nullptr;
     const bool pull = have_predictor && d->lambda_tmp != 0.f;
     dp_seq_state st = seq_state(d);
+    // (the sequence's global position / rotation live on the device: reset_device_state, set_global_pos; the staged
+    //  cur_rot below is what dp_optimize took and is kept for reference)
     if (have_predictor) {
         if (d->window < 0) { d->fail("drag_pose: temporalFutureWindow must not be negative"); return; } // (a multiple of the predictor's sample_step: dp_temporal_predict checks)
         if (d->target_window != d->window) { // (re)sized and zeroed, as drag_pose.py:238-246 does
@@ -449,31 +451,40 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     p.early_stop = 1; p.stop_eps_pos = d->stop_eps_pos; p.stop_eps_rot = d->stop_eps_rot; p.min_loss_incr = 0.00001f; // run() default
     p.max_trackers = 0;
     p.kernel = DP_KERNEL_AUTO;
-    dp_result r;
+    // one frame = a whole-sequence launch of one step: the optimise loop with the reference's while-condition and run()'s epilogue
+    // (drag_pose.py:296-402) in one kernel -- the path dragposer_amd.DragPose.run takes, so the two agree bit for bit --, then the
+    // history buffers (no joint adjustment on this path: run_drag.py:154)
+    dp_seq_frames fr;
+    std::memset(&fr, 0, sizeof(fr));
+    fr.n_steps = 1;
+    fr.tgt_pos = b.tgt_pos; fr.tgt_rot = b.tgt_rot; fr.tgt_root = nullptr; fr.w = b.w; fr.tracked = b.tracked;
+    fr.z_tgt = b.z_tgt; fr.z_tgt_step = 0; fr.z_tgt_seq = LAT;
+    dp_seq_results r;
     std::memset(&r, 0, sizeof(r));
-    r.z = dout + OUT_Z; r.z_pre = dout + OUT_ZPRE; r.pose = dout + OUT_POSE; r.disp = dout + OUT_DISP; r.world_disp = dout + OUT_WD;
-    r.world_rot = dout + OUT_WR; r.pos = dout + OUT_POS; r.loss = dout + OUT_LOSS; r.iters = (int*)(dout + OUT_ITERS);
-    float out[OUT_FLOATS];
-    dp_seq_step step; // the history buffers follow on the device (drag_pose.py:386-397); no joint adjustment on this path (run_drag.py:154)
+    r.pose_ret = (float*)d->d_state + ST_POSE; r.pos_ret = (float*)d->d_state + ST_GPOS; r.iters = (int*)(dout + OUT_ITERS); r.loss = dout + OUT_LOSS;
+    r.hist_scratch = dout + OUT_Z; // (LAT + 3 + NHGT floats)
+    static_assert(OUT_LOSS >= LAT + 3 + NHGT, "the history scratch row fits in front of the loss");
+    dp_seq_step step;
     std::memset(&step, 0, sizeof(step));
     step.adjust_joint = -1; step.adjust_target_joint = -1;
-    step.pose_ret = (float*)d->d_state + ST_POSE; step.pos_ret = (float*)d->d_state + ST_GPOS;
-    if (dp_io_upload(d->ctx, di, in, sizeof(in), nullptr) != DP_OK || dp_optimize(d->ctx, &b, &p, &r, nullptr) != DP_OK ||
-        dp_sequence_advance(d->ctx, 1, &r, &st, &step, nullptr) != DP_OK ||
-        dp_io_download(d->ctx, out, dout, sizeof(out), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
+    float head[8], ret[92];
+    if (dp_io_upload(d->ctx, di, in, sizeof(in), nullptr) != DP_OK ||
+        dp_optimize_sequence(d->ctx, 1, di + IN_Z0, &fr, &p, &st, &step, &r, nullptr) != DP_OK ||
+        dp_io_download(d->ctx, d->latent, di + IN_Z0, sizeof(d->latent), nullptr) != DP_OK ||
+        dp_io_download(d->ctx, head, (float*)d->d_state + ST_POS, sizeof(head), nullptr) != DP_OK ||
+        dp_io_download(d->ctx, ret, (float*)d->d_state + ST_POSE, sizeof(ret), nullptr) != DP_OK ||
+        dp_io_download(d->ctx, &d->last_iters, dout + OUT_ITERS, sizeof(int), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
         d->fail(std::string("drag_pose: ") + dp_last_error(d->ctx));
         return;
     }
-    // epilogue (drag_pose.py:369-396)
-    std::memcpy(d->latent, out + OUT_Z, sizeof(d->latent));
-    for (int a = 0; a < 3; ++a) d->cur_pos[a] += out[OUT_WD + a];
-    d->cur_rot = {out[OUT_WR], out[OUT_WR + 1], out[OUT_WR + 2], out[OUT_WR + 3]};
-    std::memcpy(&d->last_iters, out + OUT_ITERS, sizeof(int));
+    // the state the kernel left (drag_pose.py:369-371), mirrored on the host
+    for (int a = 0; a < 3; ++a) d->cur_pos[a] = head[ST_POS + a];
+    d->cur_rot = {head[ST_ROT], head[ST_ROT + 1], head[ST_ROT + 2], head[ST_ROT + 3]};
     d->current_index = d->window <= 0 ? 0 : (d->current_index + 1) % d->window; // drag_pose.py:399-402
     // result (run_drag.py:161-176): de-normalised root-space quaternions with the world root -> parent-local rotations
     Quat q[NJ];
     for (int j = 0; j < NJ; ++j) {
-        const float* pz = out + OUT_POSE + 4 * j;
+        const float* pz = ret + 4 * j; // the returned pose (d_state + ST_POSE)
         q[j] = {pz[0] * d->std_q[4 * j] + d->mean_q[4 * j], pz[1] * d->std_q[4 * j + 1] + d->mean_q[4 * j + 1],
                 pz[2] * d->std_q[4 * j + 2] + d->mean_q[4 * j + 2], pz[3] * d->std_q[4 * j + 3] + d->mean_q[4 * j + 3]};
     }

@@ -640,6 +640,9 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, float* fb, int gf, bool opti
 #ifndef W4_B2_RES_V
 #define W4_B2_RES_V 2
 #endif
+#ifndef W4_B2_RES_A_SEQ
+#define W4_B2_RES_A_SEQ 1
+#endif
 // SEQ (whole-sequence launches, dp_optimize_sequence): frames are SEQUENCES; the kernel loops over a.seq.n_steps frame indices,
 // carrying every sequence's state (latent, global position / rotation) from step to step in registers and LDS -- the per-frame
 // epilogue of drag_pose.py:369-402 included -- and writes each step's results to the step's slab of the output arrays.
@@ -647,6 +650,7 @@ template <int NW, bool EARLY, bool SEQ = false>
 __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 {
     static_assert(!SEQ || EARLY, "sequences run the reference's while-condition");
+    static_assert(W4_B2_RES_A_SEQ >= 1 && W4_B2_RES_A >= 1, "the first resident group of bL2 starts the chain from zero");
     __shared__ __attribute__((aligned(16))) float lds[lds_total<NW>()];
 
 #ifdef DP_PROFILE
@@ -750,7 +754,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     // accumulator registers; bL0's 5 groups in VECTOR registers -- measured +2 % over streaming them; the head of bL2 in
     // what is left of both halves).  First the forward layers (the small loads have that long to come back) ...
     f4 wL0[6], wL1[10], wL2A[15], wL2B[15], wB1[15], wz[5];
-    constexpr int B2_RES_A = W4_B2_RES_A, B2_RES_V = EARLY ? 0 : W4_B2_RES_V, B2_RES = B2_RES_A + B2_RES_V;
+    // (SEQ: the step loop around the iteration loop keeps more values alive; with every accumulator register holding a weight the
+    //  allocator starts copying weight groups around inside the iteration loop -- behind the hand-padded MFMA groups' backs.  The
+    //  head of bL2 is streamed like the rest of it there.)
+    constexpr int B2_RES_A = SEQ ? W4_B2_RES_A_SEQ : W4_B2_RES_A, B2_RES_V = EARLY ? 0 : W4_B2_RES_V, B2_RES = B2_RES_A + B2_RES_V;
     f4 wB2a[B2_RES_A > 0 ? B2_RES_A : 1], wB2v[B2_RES_V > 0 ? B2_RES_V : 1];
     const f4* wst = (const f4*)(lds + L_TAB) + lane; // group g of the image at wst[64 g] (g < GR_B2), wst[64 (g - NG_B2)] beyond bL2
     load_w<6>(wL0, wst + (S_L0 / 4) * 64);
@@ -832,8 +839,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             if (a.seq.tgt_root) { const float* rp = a.seq.tgt_root + (size_t)gfi * 3; shift = {rp[0] - gp0.x, rp[1] - gp0.y, rp[2] - gp0.z}; }
             if (b == 0) *(f4*)(fb + FB_GPOS) = f4{gp0.x, gp0.y, gp0.z, 0.f};
         }
-        trk = tracker_finish(a, fb, raw, E, cur, shift);
-        for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur, -1, shift); // (uniform, rare)
+        // (SEQ: every step, the first included, builds its tracker records in the step loop below -- ONE code path, so that a
+        //  sequence cut into launches of any lengths gives the same bits)
+        if (!SEQ) {
+            trk = tracker_finish(a, fb, raw, E, cur, shift);
+            for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur, -1, shift); // (uniform, rare)
+        } else {
+            trk = TRec{};
+        }
     }
     if (b == 0) *(f4*)(fb + FB_QS + 4 * QS_IDENT) = f4{1.f, 0.f, 0.f, 0.f};
     if (b < MAX_ROOT_CH) *(f4*)(fb + FB_BN + 4 * init_id) = init_off;
@@ -887,12 +900,13 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             const f4 gpv = *(const f4*)(fb + FB_GPOS);
             step_shift = {rp[0] - gpv.x, rp[1] - gpv.y, rp[2] - gpv.z};
         }
-        if (step > 0) { // the next frame of every sequence: its targets, a warm-started latent, a fresh Adam state (drag_pose.py:218)
+        { // this frame of every sequence: its targets, a warm-started latent, a fresh Adam state (drag_pose.py:218)
             const f4 cvs = *(const f4*)(fb + FB_CUR);
             const Q4 cur = {cvs.x, cvs.y, cvs.z, cvs.w};
             trk = tracker_finish(as, fb, tracker_fetch(as, true, gfi, tmask, E, b, gft), E, cur, step_shift);
             for (int base = 16; base < Emax; base += 16) make_tracker(as, fb, gfi, tmask, E, base + b, cur, gft, step_shift); // (uniform, rare)
-            zD = zfinD;
+            if (step > 0) zD = zfinD;
+            zfinD = zD;
             mD = f4{0.f, 0.f, 0.f, 0.f}; vD = mD;
             if (lane < LAT) {
 #pragma unroll
@@ -1105,10 +1119,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         out_consts(lds + L_OC + 20 * b, pc.itemA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, pc.itemB, pc.kindB, oA, oB);
         if (fvalid || SEQ) { // (SEQ: the clamped copies of a ragged tail keep their own state consistent; their stores are skipped below)
             const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
-            if (!SEQ || fvalid) {
-                w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY);
-                w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY);
-            }
+            w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY); // (SEQ: the copies re-store the last valid frame's rows, same values)
+            w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY);
         }
     }
     if (optimise && lane < LAT) {
@@ -1124,7 +1136,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     if (optimise && ae.iters && lane < FPW && f0 + lane < nB) ae.iters[row0 + f0 + lane] = EARLY ? es_iters : ae.n_iter;
     if (SEQ) { // the rest of run()'s epilogue (drag_pose.py:369-391), one lane per sequence: dp_sequence_advance's arithmetic
         wave_sync();
-        if (b == 0 && fvalid) {
+        if (b == 0) { // (the clamped copies of a ragged tail advance their state too -- or they would fall behind their targets,
+                      //  iterate to the limit and hold the wave up --; only their stores are skipped)
             const f4 wd = *(const f4*)(fb + FB_SWD), qw = *(const f4*)(fb + FB_SQW), gp0 = *(const f4*)(fb + FB_GPOS);
             f4 ds = *(const f4*)(fb + FB_SD);
             float gp[3] = {gp0.x + wd.x, gp0.y + wd.y, gp0.z + wd.z}; // drag_pose.py:370
@@ -1140,15 +1153,15 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                     dsp[k] += adj;
                 }
             }
-            if (ae.seq.pos_ret) { float* o = ae.seq.pos_ret + (size_t)gfo * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; }
-            {
+            if (ae.seq.pos_ret && fvalid) { float* o = ae.seq.pos_ret + (size_t)gfo * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; }
+            if (fvalid) {
                 float* o = ae.seq.hist + (size_t)gfo * (LAT + 3 + ae.seq.n_heights) + LAT;
                 o[0] = dsp[0]; o[1] = dsp[1]; o[2] = dsp[2];
                 for (int h = 0; h < ae.seq.n_heights; ++h) o[3 + h] = fb[FB_SPOS + 3 * ae.seq.height_joints[h] + 1] + gp[1];
             }
             *(f4*)(fb + FB_GPOS) = f4{gp[0], gp[1], gp[2], 0.f};
             *(f4*)(fb + FB_CUR) = qw; // drag_pose.py:371
-            if (step == ae.seq.n_steps - 1) {
+            if (step == ae.seq.n_steps - 1 && fvalid) {
                 float* o = ae.seq.global_pos + (size_t)gfi * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
                 *(f4*)(ae.seq.global_rot + (size_t)gfi * 4) = qw;
             }

@@ -243,8 +243,8 @@ class DragPose:
             stop_eps_rot=1e-2, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-3, lambda_rot=1, lambda_temporal=1,
             temporal_future_window=60, height_indices=(0, 4, 8, 13, 17, 21), joint_adjustment_indices=None,
             joint_adjustment_weight=0.01, verbose=False, out_pose=None, out_pos=None):
-        """One frame for every sequence: two kernel launches (optimise loop, epilogue) plus two row scatters of the
-        targets.  `out_pose` [S,88] / `out_pos` [S,3]: optional caller storage for the returned tensors."""
+        """One frame for every sequence: one launch for the optimise loop and the epilogue, one for the history buffers, plus two
+        row scatters of the targets.  `out_pose` [S,88] / `out_pos` [S,3]: optional caller storage for the returned tensors."""
         dev, S = self.device, self.S
         squeeze = torch.as_tensor(target_ee_pos).dim() == 2
         tp = torch.as_tensor(target_ee_pos, dtype=torch.float32, device=dev).reshape(S, -1, 3)
@@ -259,34 +259,35 @@ class DragPose:
             self._offsets_checked = True  # (a device->host round trip: once, not per frame)
 
         self._temporal_targets(temporal_future_window)
-        target_latent = self.target_latent_buffer[:, self.current_index].contiguous()
         trk["tgt_pos"].index_copy_(1, trk["mj"], tp)
         trk["tgt_rot"].index_copy_(1, trk["mj"], tR)
 
-        self._flip ^= 1  # two result sets, alternated: `last` (and the latent it carries) stays valid while the next frame runs
-        if self._out[self._flip] is None:
-            self._out[self._flip] = self.opt.allocate_outputs(S, _RUN_OUTPUTS)
-        out = self.opt.optimize(self.latent, target_latent, self.current_global_rot, trk["tgt_pos"], trk["tgt_rot"], trk["w"],
-                                trk["tracked"], n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot),
-                                lambda_tmp=float(lambda_temporal), stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot,
-                                min_loss_incr=min_loss_incr, max_trackers=E, outputs=_RUN_OUTPUTS, out=self._out[self._flip])
-        self.last = out
-        self.latent = out["z"]
-        if verbose:
-            l, it = out["loss"].cpu(), out["iters"].cpu()
-            print(f"Loss sqrt(Pos): {l[:, 0].sqrt().mean():.5f} // Loss Rot: {l[:, 1].mean():.5f} // "
-                  f"Loss Temporal: {l[:, 2].mean():.5f} // Iter: {it.float().mean():.1f}")
-
-        # ---- epilogue (drag_pose.py:369-402): one launch, state updated in place
+        # one frame = a whole-sequence launch of one step (dp_optimize_sequence): the optimise loop AND run()'s epilogue
+        # (drag_pose.py:369-402) in one kernel, the same one run_frames() uses for stretches of frames -- so cutting a sequence into
+        # calls of run() or handing it to run_frames() whole gives the same bits
         adjust = None
         if joint_adjustment_indices is not None:
             joint_index, ee_index = joint_adjustment_indices
             adjust = (int(joint_index), int(trk["mj_host"][ee_index]), float(joint_adjustment_weight))
         pose = out_pose if out_pose is not None else torch.empty(S, 88, device=dev)
         gpos = out_pos if out_pos is not None else torch.empty(S, 3, device=dev)
-        self.opt.sequence_advance(out, self.current_global_pos, self.current_global_rot, self.latent_buffer, self.displacement_buffer,
-                                  self.heights_buffer, tuple(int(h) for h in height_indices), pose_ret=pose, pos_ret=gpos,
-                                  adjust=adjust, tgt_pos=trk["tgt_pos"])
+        self._flip ^= 1  # two result sets, alternated: `last` stays valid while the next frame runs
+        if self._out[self._flip] is None:
+            self._out[self._flip] = dict(iters=torch.empty(1, S, dtype=torch.int32, device=dev), loss=torch.empty(1, S, 3, device=dev),
+                                         scratch=torch.empty(1, S, LATENT + 3 + len(height_indices), device=dev))
+        o = self._out[self._flip]
+        z_tgt = self.target_latent_buffer[:, self.current_index:]
+        self.opt.optimize_sequence(self.latent, trk["tgt_pos"].unsqueeze(0), trk["tgt_rot"].unsqueeze(0), None, trk["w"], trk["tracked"], z_tgt,
+                                   (0, (int(temporal_future_window) + 1) * LATENT), self.current_global_pos, self.current_global_rot,
+                                   self.latent_buffer, self.displacement_buffer, self.heights_buffer, tuple(int(h) for h in height_indices),
+                                   n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot), lambda_tmp=float(lambda_temporal),
+                                   stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot, min_loss_incr=min_loss_incr, adjust=adjust,
+                                   pose_ret=pose.unsqueeze(0), pos_ret=gpos.unsqueeze(0), iters=o["iters"], loss=o["loss"], scratch=o["scratch"])
+        self.last = dict(iters=o["iters"][0], loss=o["loss"][0], z=self.latent)
+        if verbose:
+            l, it = self.last["loss"].cpu(), self.last["iters"].cpu()
+            print(f"Loss sqrt(Pos): {l[:, 0].sqrt().mean():.5f} // Loss Rot: {l[:, 1].mean():.5f} // "
+                  f"Loss Temporal: {l[:, 2].mean():.5f} // Iter: {it.float().mean():.1f}")
         self.current_index = 0 if temporal_future_window == 0 else (self.current_index + 1) % temporal_future_window
         if squeeze and S == 1:
             return pose[0], gpos[0]
