@@ -80,7 +80,8 @@ class DpSeqFrames(C.Structure):
 
 
 class DpSeqResults(C.Structure):
-    _fields_ = [("pose_ret", C.c_void_p), ("pos_ret", C.c_void_p), ("iters", C.c_void_p), ("loss", C.c_void_p), ("hist_scratch", C.c_void_p)]
+    _fields_ = [("pose_ret", C.c_void_p), ("pos_ret", C.c_void_p), ("world_rot", C.c_void_p), ("iters", C.c_void_p), ("loss", C.c_void_p),
+                ("hist_scratch", C.c_void_p)]
 
 
 class DpTemporalLayer(C.Structure):

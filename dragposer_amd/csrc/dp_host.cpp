@@ -687,7 +687,7 @@ extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const
     KArgs k;
     fill_model_args(ctx, k);
     k.z0 = latent; k.z_tgt = fr->z_tgt; k.cur_rot = st->global_rot; k.tgt_pos = fr->tgt_pos; k.tgt_rot = fr->tgt_rot; k.w = fr->w; k.tracked = fr->tracked;
-    k.z = latent; k.pose = out->pose_ret; k.iters = out->iters; k.loss = out->loss;
+    k.z = latent; k.pose = out->pose_ret; k.world_rot = out->world_rot; k.iters = out->iters; k.loss = out->loss;
     k.n_frames = n_seq; k.n_iter = p->n_iter; k.mode = 0;
     k.lam_rot = p->lambda_rot; k.lam_tmp = p->lambda_tmp; k.ctmp = 2.f * p->lambda_tmp / 24.f;
     k.beta2 = p->beta2; k.one_m_b1 = (float)(1.0 - (double)p->beta1); k.one_m_b2 = (float)(1.0 - (double)p->beta2);

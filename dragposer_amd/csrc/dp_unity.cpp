@@ -54,6 +54,7 @@ struct DragPoser {
     bool warned_temporal = false;
     int current_index = 0;   // frame inside the temporal window (drag_pose.py:399-402)
     int target_window = -1;  // window the device target buffer was sized for
+    bool pull_was_on = false; // the temporal term was on in the previous frame
     // state (drag_pose.py:47-64)
     bool initialised = false;
     float latent[LAT] = {0}, cur_pos[3] = {0, 0, 0};
@@ -198,7 +199,9 @@ bool reset_device_state(DragPoser* d)
     st[ST_ROT] = d->cur_rot.w; st[ST_ROT + 1] = d->cur_rot.x; st[ST_ROT + 2] = d->cur_rot.y; st[ST_ROT + 3] = d->cur_rot.z;
     for (int t = 0; t < HIST; ++t) std::memcpy(&st[ST_LAT + t * LAT], d->latent, sizeof(d->latent));
     d->current_index = 0;
-    return dp_io_upload(d->ctx, d->d_state, st.data(), st.size() * sizeof(float), nullptr) == DP_OK && dp_stream_sync(d->ctx, nullptr) == DP_OK;
+    return dp_io_upload(d->ctx, d->d_state, st.data(), st.size() * sizeof(float), nullptr) == DP_OK &&
+           dp_io_upload(d->ctx, (float*)d->d_out + OUT_Z, d->latent, sizeof(d->latent), nullptr) == DP_OK && // the latent is device-resident (in/out of every frame)
+           dp_stream_sync(d->ctx, nullptr) == DP_OK;
 }
 
 // <modelPath>/temporal.bin (DPM1, written by tools/export_temporal_bin.py from the reference's temporal.pt): the state_dict of
@@ -416,14 +419,18 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     b.z0 = di + IN_Z0; b.z_tgt = di + IN_ZT; b.cur_rot = di + IN_ROT; b.tgt_pos = di + IN_TP; b.tgt_rot = di + IN_TR; b.w = di + IN_W;
     b.tracked = (const unsigned char*)(di + IN_TRK);
     // temporal target block (drag_pose.py:234-294): a prediction every `window` frames, one row of it per frame
-    // The reference runs its predictor at current_index == 0 whatever lambda_temporal is (drag_pose.py:235-291), so the
-    // target buffer always holds the current window's prediction when the pull is switched on mid-window; so does this.
+    // The reference runs its predictor at current_index == 0 whatever lambda_temporal is (drag_pose.py:235-291); a prediction is a
+    // 0.2 ms launch, so this plug-in makes it only while the pull term is on -- and when the term is switched on in the middle of
+    // a window (Unity's SetLambdas) it restarts the window, so that the first pulled frame has a fresh prediction instead of a
+    // stale or zero-filled buffer.
     const bool have_predictor = d->temporal != nullptr;
     const bool pull = have_predictor && d->lambda_tmp != 0.f;
+    if (pull && !d->pull_was_on) d->current_index = 0;
+    d->pull_was_on = pull;
     dp_seq_state st = seq_state(d);
     // (the sequence's global position / rotation live on the device: reset_device_state, set_global_pos; the staged
     //  cur_rot below is what dp_optimize took and is kept for reference)
-    if (have_predictor) {
+    if (pull) {
         if (d->window < 0) { d->fail("drag_pose: temporalFutureWindow must not be negative"); return; } // (a multiple of the predictor's sample_step: dp_temporal_predict checks)
         if (d->target_window != d->window) { // (re)sized and zeroed, as drag_pose.py:238-246 does
             // Unity's SetLambdas may change the window mid-window.  The reference keeps current_index and then indexes the
@@ -443,7 +450,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
             return;
         }
         if (d->current_index > d->window) { d->fail("drag_pose: temporal window index out of range"); return; } // (cannot happen: see above)
-        if (pull) b.z_tgt = (float*)d->d_target + (size_t)d->current_index * LAT;
+        b.z_tgt = (float*)d->d_target + (size_t)d->current_index * LAT;
     }
     dp_params p;
     p.n_iter = d->max_iter; p.lr = d->lr; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f;
@@ -459,27 +466,29 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     fr.n_steps = 1;
     fr.tgt_pos = b.tgt_pos; fr.tgt_rot = b.tgt_rot; fr.tgt_root = nullptr; fr.w = b.w; fr.tracked = b.tracked;
     fr.z_tgt = b.z_tgt; fr.z_tgt_step = 0; fr.z_tgt_seq = LAT;
+    // everything the host needs back lands in ONE device block (one download per frame): the latent (device-resident, in/out),
+    // the returned pose, the global position and rotation after the step, the iteration count
     dp_seq_results r;
     std::memset(&r, 0, sizeof(r));
-    r.pose_ret = (float*)d->d_state + ST_POSE; r.pos_ret = (float*)d->d_state + ST_GPOS; r.iters = (int*)(dout + OUT_ITERS); r.loss = dout + OUT_LOSS;
-    r.hist_scratch = dout + OUT_Z; // (LAT + 3 + NHGT floats)
-    static_assert(OUT_LOSS >= LAT + 3 + NHGT, "the history scratch row fits in front of the loss");
+    r.pose_ret = dout + OUT_POSE; r.pos_ret = dout + OUT_WD; r.world_rot = dout + OUT_WR; r.iters = (int*)(dout + OUT_ITERS); r.loss = dout + OUT_LOSS;
+    r.hist_scratch = dout + OUT_POS; // (LAT + 3 + NHGT floats of scratch: the block's joint-position area is unused on this path)
+    static_assert(NJ * 3 >= LAT + 3 + NHGT, "the history scratch row fits");
     dp_seq_step step;
     std::memset(&step, 0, sizeof(step));
     step.adjust_joint = -1; step.adjust_target_joint = -1;
-    float head[8], ret[92];
+    float out[OUT_FLOATS];
     if (dp_io_upload(d->ctx, di, in, sizeof(in), nullptr) != DP_OK ||
-        dp_optimize_sequence(d->ctx, 1, di + IN_Z0, &fr, &p, &st, &step, &r, nullptr) != DP_OK ||
-        dp_io_download(d->ctx, d->latent, di + IN_Z0, sizeof(d->latent), nullptr) != DP_OK ||
-        dp_io_download(d->ctx, head, (float*)d->d_state + ST_POS, sizeof(head), nullptr) != DP_OK ||
-        dp_io_download(d->ctx, ret, (float*)d->d_state + ST_POSE, sizeof(ret), nullptr) != DP_OK ||
-        dp_io_download(d->ctx, &d->last_iters, dout + OUT_ITERS, sizeof(int), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
+        dp_optimize_sequence(d->ctx, 1, dout + OUT_Z, &fr, &p, &st, &step, &r, nullptr) != DP_OK ||
+        dp_io_download(d->ctx, out, dout, sizeof(out), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
         d->fail(std::string("drag_pose: ") + dp_last_error(d->ctx));
         return;
     }
     // the state the kernel left (drag_pose.py:369-371), mirrored on the host
-    for (int a = 0; a < 3; ++a) d->cur_pos[a] = head[ST_POS + a];
-    d->cur_rot = {head[ST_ROT], head[ST_ROT + 1], head[ST_ROT + 2], head[ST_ROT + 3]};
+    std::memcpy(d->latent, out + OUT_Z, sizeof(d->latent));
+    for (int a = 0; a < 3; ++a) d->cur_pos[a] = out[OUT_WD + a];
+    d->cur_rot = {out[OUT_WR], out[OUT_WR + 1], out[OUT_WR + 2], out[OUT_WR + 3]};
+    std::memcpy(&d->last_iters, out + OUT_ITERS, sizeof(int));
+    const float* ret = out + OUT_POSE;
     d->current_index = d->window <= 0 ? 0 : (d->current_index + 1) % d->window; // drag_pose.py:399-402
     // result (run_drag.py:161-176): de-normalised root-space quaternions with the world root -> parent-local rotations
     Quat q[NJ];

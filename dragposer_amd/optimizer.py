@@ -229,6 +229,7 @@ def _optimize_sequence(self, latent, tgt_pos, tgt_rot, tgt_root, w, tracked, z_t
         step.adjust_joint, step.adjust_target_joint, step.adjust_weight = int(adjust[0]), int(adjust[1]), float(adjust[2])
     res = _lib.DpSeqResults()
     outs = {}
+    res.world_rot = None
     for name, t, shape, dtype in (("pose_ret", pose_ret, (T, S, 88), torch.float32), ("pos_ret", pos_ret, (T, S, 3), torch.float32),
                                   ("iters", iters, (T, S), torch.int32), ("loss", loss, (T, S, 3), torch.float32)):
         t = t if t is not None else torch.empty(shape, dtype=dtype, device=dev)

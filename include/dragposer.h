@@ -213,6 +213,7 @@ typedef struct dp_seq_frames {   /* DEVICE pointers; T = n_steps */
 typedef struct dp_seq_results {  /* DEVICE pointers, per step; any but hist_scratch may be NULL */
     float* pose_ret;     /* [T][S][88] what run() returns (root channels = the normalised world rotation) */
     float* pos_ret;      /* [T][S][3]  returned global position */
+    float* world_rot;    /* [T][S][4]  global rotation after the step (= the state's global_rot then) */
     int* iters;          /* [T][S]     iterations executed */
     float* loss;         /* [T][S][3]  losses of the frame's last executed iteration */
     float* hist_scratch; /* [T][S][24 + 3 + NH] floats of caller-owned scratch (the steps' history rows before they are appended) */

@@ -33,11 +33,35 @@ def _kernel_notes(src, tmp_path):
 def test_optimise_kernel_keeps_its_register_budget(tmp_path):
     notes = _kernel_notes("dp_w4.hip", tmp_path)
     kernels = {k: v for k, v in notes.items() if "dp_w4_kernel" in k}
-    assert len(kernels) == 2, list(notes)  # <4, false> and <4, true> (early stop)
+    assert len(kernels) == 3, list(notes)  # <4, false>, <4, true> (early stop) and <4, true, true> (whole-sequence launches)
     for name, n in kernels.items():
+        assert n["lds"] <= 160 * 1024, (name, n)
+        if name.endswith("ELb1ELb1EEv5KArgs"):
+            # the step loop around the iteration loop keeps more alive: some spills (outside the iteration loop) are accepted there;
+            # inside it the hand-padded MFMA groups must not be interleaved with copies of their operands (checked below)
+            assert n["vspill"] <= 40 and n["scratch"] <= 160, (name, n)
+            continue
         assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
         assert n["agpr"] == 256, (name, n)          # every accumulator register holds a resident weight
-        assert n["lds"] <= 160 * 1024, (name, n)
+
+
+def test_sequence_kernel_moves_no_weight_inside_the_iteration_loop(tmp_path):
+    """Found the hard way (round 3): with every accumulator register holding a resident weight, the whole-sequence instantiation made
+    the register allocator copy weight groups (v_accvgpr_mov) right in front of the inline-asm MFMA groups that read them -- a
+    hazard the hand-padded groups do not cover, and the results were wrong.  It keeps one resident group of bL2 now; this test
+    fails if a compiler or source change brings accumulator-register copies or scratch reloads back between the loop's MFMAs."""
+    out = tmp_path / "dp_w4.s"
+    flags = [f for f in G.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call(["hipcc", *flags, "-S", "--cuda-device-only", "-o", str(out), os.path.join(G.CSRC, "dp_w4.hip")],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = out.read_text().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z12dp_w4_kernelILi4ELb1ELb1EEv5KArgs:"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    body = lines[start:end]
+    mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+    loop = body[mf[40]:mf[-1]]  # (the first MFMAs belong to the set-up's transposes)
+    bad = [l.strip() for l in loop if "v_accvgpr_mov" in l or "v_accvgpr_write" in l or "scratch_" in l]
+    assert not bad, bad[:8]
 
 
 def test_temporal_kernel_variants_fit_their_occupancy(tmp_path):

@@ -73,6 +73,24 @@ def _kink_distance(b, frames, n_iter, lam):
     return np.array(out)
 
 
+def _tiny_gradient(b, frames, lam, n_first=6):
+    """The second, rarer mechanism (profiles/r03_soak_divergence.txt: 3 of 20 missed frames, all below 0.16 mm): Adam's first steps
+    move every component by about lr * sign(g) whatever |g| is, so a component of dL/dz within rounding of zero (typical smallest
+    component: 1e-4) gives two correct implementations different steps.  Smallest |dL/dz_k| over the first iterations of the fp64
+    oracle's trajectory of each given frame."""
+    A = AnalyticOracle(precision="f64")
+    out = []
+    for f in frames:
+        a = [b[k][f:f + 1] for k in KEYS]
+        mg = np.inf
+        for t in range(n_first):
+            z = a[0] if t == 0 else A.optimize(*a, t, lam_tmp=lam)["z_final"]
+            _, g = A.grad(z, *a[1:], 1.0, lam)
+            mg = min(mg, float(np.abs(g).min()))
+        out.append(mg)
+    return np.array(out)
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a MI355X"
@@ -250,18 +268,21 @@ def test_full_size_batch_properties(opt, dev, golden_dir):
     # (module docstring): on a frame whose trajectory takes one within fp32 rounding of zero, two correct implementations part
     # ways -- the reference's own fp32 and fp64 runs do on 1 of these 4096 frames (frame 2327, 3.2 mm), each other pair of
     # implementations on its own one or two.  So: at most 4 frames (0.1 %) above 0.05 mm, none above 5 mm, and every one of them
-    # either reference-flagged or showing the mechanism (|pre-activation| < 5e-6 on its fp64 trajectory; typical frames 3e-4).
+    # either reference-flagged or showing a mechanism: |pre-activation| < 5e-6 on its fp64 trajectory (typical frames 3e-4), or
+    # -- rarer, small -- a component of dL/dz below 1e-5 in the first iterations (`_tiny_gradient`).  Where a miss starts and what
+    # sits there, for the 20 missed frames of 12 more seeds: profiles/r03_soak_divergence.txt (tools/soak_divergence.py).
     e = _mm(o1["pos"], ref["pos"])
     err = e.max(axis=1)
     ref_flag = np.zeros(4096, bool)
     ref_flag[ref["sens_frames"]] = True
     allowance = np.nonzero(err > 0.05)[0]
     kink = _kink_distance(b, allowance, 50, 0.02)
+    tiny = _tiny_gradient(b, allowance, 0.02)
     print(f"4096 frames vs the reference's fp32 run: mean {e.mean():.5f} mm, p99 {np.percentile(e, 99):.5f}, p99.9 {np.percentile(e, 99.9):.5f}, max {e.max():.3f}; "
           f"above 0.05 mm: frames {allowance.tolist()} ({np.round(err[allowance], 3).tolist()} mm, smallest |pre-activation| {kink.tolist()}); "
           f"the reference's own fp32 vs fp64 runs: frames {ref['sens_frames'].tolist()} ({np.round(ref['ref32_vs_ref64_mm'][ref['sens_frames']], 3).tolist()} mm)")
     assert len(allowance) <= 4 and err.max() <= 5.0, (allowance, err.max())
-    assert all(ref_flag[f] or k < 5e-6 for f, k in zip(allowance, kink)), (allowance, kink)
+    assert all(ref_flag[f] or k < 5e-6 or t < 1e-5 for f, k, t in zip(allowance, kink, tiny)), (allowance, kink, tiny)
     assert np.percentile(err, 99.8) <= 0.05 and err[err <= 0.05].mean() <= 0.002, (np.percentile(err, 99.8), err.mean())
     np.testing.assert_allclose(o1["z"][err <= 0.05], ref["z_final"][err <= 0.05], atol=2e-4)  # (5e-5 on all but one of 98 232 components: flat latent directions)
     np.testing.assert_allclose(o1["loss"][err <= 0.05], ref["loss_last"][err <= 0.05], rtol=2e-3, atol=1e-8)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r02/).
+# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r03/).
 # rocprofv3: program directly after `--`; counters in their own passes with --kernel-trace only.
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/prof_r02
+O=gpurun_out/prof_r03
 rm -rf $O && mkdir -p $O
 # 1. kernel-trace stats of the default bench command
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
@@ -24,7 +24,7 @@ for fr in 256 1024 2048 4096 8192 16384 65536; do
 done > $O/batch_sweep.txt
 echo "sweep done"
 # 4. phase stamps (diagnostic build): the product's kernel, and the previous decomposition for comparison
-( SPECS="4096:0:w4 1024:0:w4" bash tools/phase_profile.sh; echo "---- previous decomposition (DP_KERNEL=8)"; PWAVE=0 SPECS="4096:0:8" bash tools/phase_profile.sh ) > $O/phase_cycles.txt 2>&1
+( SPECS="4096:0:w4 1024:0:w4 4096:0:8" bash tools/phase_profile.sh ) > $O/phase_cycles.txt 2>&1
 echo "phases done"
 # 5. per-launch cost against the iteration count
 python3 tools/time_iters.py 4096 > $O/time_vs_iters.txt 2>&1
@@ -40,4 +40,19 @@ python3 tools/time_temporal.py 2>&1 | grep "^window" > $O/temporal_predictor_tim
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tstats --output-format csv -- python3 tools/time_temporal.py --native-only > $O/tstats.log 2>&1
 grep "dp_temporal_kernel\|\"Name\"" $(find $O/tstats -name "*kernel_stats.csv" | head -1) > $O/temporal_kernel_stats.csv
 echo "temporal done"
+# 8. the 16-frames-per-wave kernel: BASELINE config 5 through bench.py (the JSON line), kernel trace, batch sweep of both kernels, PMC passes
+python3 bench.py --config s4 --frames 16384 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_s4_16384.json 2> /dev/null
+python3 bench.py --config s4 --frames 65536 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_s4_65536.json 2> /dev/null
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/s4stats --output-format csv -- python3 bench.py --config s4 --frames 16384 --steps 20 --no-cpu-baseline > $O/bench_s4_under_rocprof.json 2> $O/s4stats.log
+grep "dp_w16_kernel\|dp_w4_kernel\|\"Name\"" $(find $O/s4stats -name "*kernel_stats.csv" | head -1) > $O/bench_s4_kernel_stats.csv
+python3 tools/w16_sweep.py 4096 8192 16384 32768 65536 131072 > $O/w16_sweep.txt 2>&1
+bash tools/w16_pmc.sh 16384 $O/w16_pmc_16384 > $O/w16_pmc_16384.txt 2>&1
+bash tools/w16_pmc.sh 65536 $O/w16_pmc_65536 > $O/w16_pmc_65536.txt 2>&1
+echo "w16 done"
+# 9. sequences: the whole operator in lock-step, the cost of a step of a whole-sequence launch, the plug-in
+python3 tools/throughput_sequences.py 6 2>&1 | grep "trackers" > $O/sequence_throughput.txt
+python3 tools/throughput_sequences.py 3 2>&1 | grep "trackers" >> $O/sequence_throughput.txt
+python3 tools/seq_timing.py 2>&1 | grep "S =\|steps in" > $O/sequence_step_cost.txt
+python3 tools/plugin_latency.py > $O/plugin_latency.txt 2>&1 || true
+echo "sequences done"
 ls $O

@@ -15,7 +15,7 @@ NAMES = ["L0 mfma", "bar1", "L1 load+mfma", "bar2", "L2 load+mfma", "bar3", "P3a
          "P3c gather/backward/out", "bar4", "bL2", "bar5", "bL1", "bar6", "bL0", "bar7", "Adam"]
 NAMES_W4 = ["L0 (transpose, 24 steps, lrelu)", "L1 (40 steps)", "L2 (120 steps, 2 transposes)", "P3 stage 1 normalise/bones", "P3 stage 2 tracker terms",
             "P3 stage 3 gather/backward", "bL2 (104 steps)", "bL1 (60 steps)", "bL0 (40 steps)", "Adam"]
-if os.environ.get("DP_KERNEL") == "w4":
+if os.environ.get("PHASE_KERNEL", "w4") == "w4":
     NAMES = NAMES_W4
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 MAXT = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # tracker hint: > 0 selects dp_kernel4 (DP_KERNEL=4x1|4x2 forces a variant)
@@ -37,7 +37,7 @@ tot = p.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:26s} {p[:, i].mean():8.0f}  {100 * p[:, i].mean() / tot.mean():5.1f}%")
-if os.environ.get("DP_KERNEL") == "w4":
+if os.environ.get("PHASE_KERNEL", "w4") == "w4":
     print(f"  per launch: entry -> first iteration {raw[:, 10].mean() * N:.0f} cycles, last iteration -> stores done {raw[:, 11].mean() * N:.0f} cycles "
           f"(max over workgroups {raw[:, 10].max() * N:.0f} / {raw[:, 11].max() * N:.0f})")
     print(f"  shader clock held over the loop: {raw[:, 17].mean() / raw[:, 16].mean() * 0.1:.3f} GHz (s_memtime / s_memrealtime)")

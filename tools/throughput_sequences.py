@@ -37,9 +37,10 @@ for S in (1, 64, 256, 1024):
             m[key] = base["m"][key][o:]
         q["m"] = m
         seqs.append(q)
-    for native in (True, False):
-        args.torch_temporal = not native
+    for native, per_frame in ((True, False), (True, True), (False, True)):
+        args.torch_temporal, args.per_frame = not native, per_frame
         res, elapsed, lam, _ = E.run_sequences(args, seqs, opt, pack, cfg)
         it = np.mean([r["iters"].mean() for r in res])
         print(f"{which} trackers, lambda_temporal {lam}, window {cfg['temporal_future_window']}: S={S:5d} sequences x {L} frames, "
-              f"{'native' if native else 'torch '} temporal block: {elapsed:7.3f} s = {S * L / elapsed:10.0f} frames/s ({it:.1f} iterations per frame)", flush=True)
+              f"{'native' if native else 'torch '} temporal block, {'host-driven frame loop' if per_frame else 'frame loop on the device '}: "
+              f"{elapsed:7.3f} s = {S * L / elapsed:10.0f} frames/s ({it:.1f} iterations per frame)", flush=True)
