@@ -142,3 +142,30 @@ def test_temporal_predictor_argument_checks_and_no_cpu_fallback():
         with pytest.raises(Exception) as e:  # a well-formed model, no device: refused, not emulated
             NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
         assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_rotation_target_validation():
+    """LatentOptimizer.optimize(validate_targets=True) -> check_rotation_targets: the kernels evaluate |R - T|^2 in its quaternion
+    form, equal to the reference's element-wise form only for rotation matrices (include/dragposer.h: dp_batch.tgt_rot)"""
+    from dragposer_amd.optimizer import check_rotation_targets
+
+    rs = np.random.RandomState(0)
+    q = rs.randn(5, 22, 4)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=-1).astype(np.float32)
+    trk = np.zeros((5, 22), np.uint8)
+    trk[:, [0, 3, 7]] = 1
+    check_rotation_targets(torch.tensor(R), torch.tensor(trk))  # rotations: passes
+    bad = R.copy()
+    bad[2, 5] *= 1.5  # an untracked joint may hold anything
+    check_rotation_targets(torch.tensor(bad), torch.tensor(trk))
+    bad[2, 3] *= 1.01  # a tracked one must be orthonormal ...
+    with pytest.raises(ValueError):
+        check_rotation_targets(torch.tensor(bad), torch.tensor(trk))
+    refl = R.copy()
+    refl[1, 7, 0:3] *= -1  # ... and proper (det +1)
+    with pytest.raises(ValueError):
+        check_rotation_targets(torch.tensor(refl), torch.tensor(trk))
+    check_rotation_targets(torch.tensor(R), torch.zeros(5, 22, dtype=torch.uint8))  # nothing tracked: nothing to check
