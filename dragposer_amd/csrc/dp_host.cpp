@@ -593,7 +593,6 @@ static int launch(dp_ctx* ctx, KArgs& k, void* stream, int kernel = DP_KERNEL_W4
     // (8 waves, 128 frames per workgroup): one wave's matrix phases under the other's vector phases
     const int w16_waves = k.n_frames > ctx->n_cu * 4 * dp_w16_frames_per_wave() ? 8 : 4;
     if (kernel == DP_KERNEL_W16) ctx->last_kernel = 16 * (w16_waves / 4);
-    k.w16_stagger = 0; // (a start delay for the second half of the waves: measured, no effect -- profiles/r03_w16_stagger.txt)
     hipError_t e = kernel == DP_KERNEL_W16 ? dp_launch_w16(&k, (hipStream_t)stream, w16_waves) : dp_launch_w4(&k, (hipStream_t)stream);
 #endif
     if (e != hipSuccess) return fail(ctx, DP_ERR_LAUNCH, std::string("kernel launch: ") + hipGetErrorString(e));

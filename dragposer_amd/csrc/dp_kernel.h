@@ -50,7 +50,6 @@ struct KArgs {
     int* iters;
     float* dbg;
     int n_frames, n_iter, mode; // mode 0: optimise, 1: forward only (n_iter = 1)
-    int w16_stagger;            // dp_w16, two waves per SIMD: the younger half of a workgroup starts this many x 1024 cycles late
     int early_stop;             // per-frame while-condition of drag_pose.py:300-304
     float stop_eps_pos, stop_eps_rot, min_loss_incr;
     float lam_rot, lam_tmp, ctmp; // ctmp = 2 lam_tmp / 24

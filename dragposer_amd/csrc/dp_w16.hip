@@ -238,12 +238,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 
     __syncthreads();
     if (f0 >= nB) return; // (uniform per wave; no barrier below)
-    // Two waves per SIMD run the same program; released together by the barrier they would meet in the same phase every
-    // iteration -- matrix work beside matrix work, vector beside vector.  The second half of the workgroup (the partners of waves
-    // 0..3) starts late by about half an iteration, so that one wave's matrix phases fall on the other's vector phases.
-    if (WPS == 2 && wave >= NW / 2)
-        for (int k = 0; k < a.w16_stagger; ++k) __builtin_amdgcn_s_sleep(16);
-
+    // (Two waves per SIMD run the same program from the same barrier; a start delay for the second half of the workgroup -- so that one
+    //  wave's matrix phases fall on the other's vector phases -- was measured and changes nothing: profiles/r03_w16_stagger.txt.)
     const float* lbias = (const float*)lds + L16_BIAS;
     Q4 q[NTY];       // unit quaternions of my slots (displacement slot: the de-normalised displacement in w, x, y)
     float inv[NTY];  // 1 / |raw quaternion|
