@@ -125,7 +125,9 @@ typedef struct dp_params {
  *   DP_KERNEL_W16  16 frames per wavefront, decoder on v_mfma_f32_16x16x32_bf16 in split precision (every fp32 operand the
  *                  exact sum of three bf16 terms, six term products per block accumulated in fp32): fixed iteration count
  *                  only, the reference's 22-joint skeleton only; DP_ERR_UNSUPPORTED otherwise.  Pays from ~8192 frames.
- *   DP_KERNEL_AUTO W16 for bf16-weight contexts (DP_WEIGHTS_BF16) with at least 8192 frames and no early stop, W4 otherwise. */
+ *   DP_KERNEL_AUTO W16 from 8192 frames without early stop (either weight type: both kernels compute in fp32-equivalent
+ *                  arithmetic and are held to the same reference run, tests/test_hip_parity.py::test_full_size_batch_properties),
+ *                  W4 otherwise -- BASELINE's 1024- and 4096-frame batches, every early-stop and sequence launch. */
 #define DP_KERNEL_AUTO 0
 #define DP_KERNEL_W4 1
 #define DP_KERNEL_W16 2

@@ -19,8 +19,10 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "S
 done
 python3 tools/pmc_summary.py $O/pmc_per_launch.json $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 $O/pmc6 $O/pmc7 > /dev/null
 # 3. batch sweep
-for fr in 256 1024 2048 4096 8192 16384 65536; do
-  python3 bench.py --frames $fr --steps 20 --warmup 3 --no-cpu-baseline --no-parity | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
+# (the library's own kernel choice: dp_w4 up to 4096 frames, dp_w16 from 8192; then dp_w4 forced at the large sizes for comparison)
+for spec in 256:auto 1024:auto 2048:auto 4096:auto 8192:auto 16384:auto 65536:auto 8192:w4 16384:w4 65536:w4; do
+  fr=${spec%%:*}; kn=${spec##*:}
+  python3 bench.py --frames $fr --kernel $kn --steps 20 --warmup 3 --no-cpu-baseline --no-parity | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '--kernel $kn:', '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
 done > $O/batch_sweep.txt
 echo "sweep done"
 # 4. phase stamps (diagnostic build): the product's kernel, and the previous decomposition for comparison
