@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/coissue_probe tools/ubench/coissue_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <utility>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -13,10 +14,10 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 template <class F, int... I> DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-enum { K_FMA, K_MUL, K_ADD, K_SUB, K_AND, K_LSHL, K_CVTPK, K_CNDMASK, K_MOV, K_ACCRD, K_PKMUL, K_PKFMA, K_RSQ, K_MED3, K_BPERM, K_FMAC, K_MULE64, K_PERM32, K_NKINDS };
+enum { K_FMA, K_MUL, K_ADD, K_SUB, K_AND, K_LSHL, K_CVTPK, K_CNDMASK, K_MOV, K_ACCRD, K_PKMUL, K_PKFMA, K_RSQ, K_MED3, K_BPERM, K_FMAC, K_MULE64, K_PERM32, K_DOT2C, K_DOT2, K_PERMB, K_CVTF32, K_NKINDS };
 static const char* NAMES[] = {"v_fma_f32", "v_mul_f32_e32", "v_add_f32_e32", "v_sub_f32_e32", "v_and_b32", "v_lshlrev_b32", "v_cvt_pk_bf16_f32", "v_cndmask_b32",
                               "v_mov_b32", "v_accvgpr_read_b32", "v_pk_mul_f32", "v_pk_fma_f32", "v_rsq_f32", "v_med3_f32", "ds_bpermute_b32", "v_fmac_f32_e32",
-                              "v_mul_f32_e64 (neg)", "v_permlane32_swap"};
+                              "v_mul_f32_e64 (neg)", "v_permlane32_swap", "v_dot2c_f32_bf16", "v_dot2_f32_bf16", "v_perm_b32", "v_cvt_f32_bf16"};
 struct St { f2 v[8]; unsigned u[8]; f4 a; };
 template <int KIND, int I> DEV void op(St& s, f2 m, f2 c)
 {
@@ -39,6 +40,10 @@ template <int KIND, int I> DEV void op(St& s, f2 m, f2 c)
     if constexpr (KIND == K_FMAC) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(s.v[i].x) : "v"(m.x), "v"(c.x));
     if constexpr (KIND == K_MULE64) asm volatile("v_mul_f32_e64 %0, -%1, %0" : "+v"(s.v[i].x) : "v"(m.x));
     if constexpr (KIND == K_PERM32) asm volatile("v_permlane32_swap_b32_e32 %0, %1" : "+v"(s.v[i].x), "+v"(s.v[i].y));
+    if constexpr (KIND == K_DOT2C) asm volatile("v_dot2c_f32_bf16_e32 %0, %1, %2" : "+v"(s.v[i].x) : "v"(0xbf80u), "v"(s.u[i]));
+    if constexpr (KIND == K_DOT2) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(s.v[i].x) : "v"(0xbf80u), "v"(s.u[i]));
+    if constexpr (KIND == K_PERMB) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s.u[i]) : "v"(s.v[i].x), "v"(s.v[i].y), "v"(0x07060302u));
+    if constexpr (KIND == K_CVTF32) asm volatile("v_cvt_f32_bf16_e32 %0, %1" : "=v"(s.v[i].x) : "v"(s.u[i]));
 }
 DEV void mfma(f4& acc, const s8v& a, const s8v& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
 DEV void init(St& s, int l)
