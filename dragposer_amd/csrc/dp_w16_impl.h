@@ -156,9 +156,14 @@ template <int LAYER, int N, int NEXT, bool PREF> DEV f4 out_tile(const u4* img, 
 }
 constexpr int pair_of(int layer, int n) { return PAIR0[layer] + n * NKB[layer]; }
 
+// component by component: an f4 * f4 becomes two v_pk_mul_f32, and a packed fp32 instruction cannot issue while a bf16 MFMA is in
+// flight -- its own wave's or the partner wave's (profiles/r03_coissue_probe.txt: paired = serial for v_pk_*)
+DEV f4 smul(f4 a, f4 b) { return f4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+DEV f4 smul(f4 a, float b) { return f4{a.x * b, a.y * b, a.z * b, a.w * b}; }
+DEV f4 pull(f4 g, float c, f4 z, f4 zt) { return f4{g.x + c * (z.x - zt.x), g.y + c * (z.y - zt.y), g.z + c * (z.z - zt.z), g.w + c * (z.w - zt.w)}; } // temporal term
 DEV f4 lrelu_factor16(f4 x)
 { // x > 0 ? 1 : 0.2 as med3(x * 2^127, 0.2, 1) (dp_w4.hip)
-    const f4 t = x * 0x1p127f;
+    const f4 t = smul(x, 0x1p127f);
     return f4{__builtin_amdgcn_fmed3f(t.x, 0.2f, 1.f), __builtin_amdgcn_fmed3f(t.y, 0.2f, 1.f), __builtin_amdgcn_fmed3f(t.z, 0.2f, 1.f),
               __builtin_amdgcn_fmed3f(t.w, 0.2f, 1.f)};
 }
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         a0[1] = out_tile<L0, 1, pair_of(L0, 2), PREF>(img, wq, bias_row(lbias, 1, g), bz);
         a0[2] = out_tile<L0, 2, pair_of(L1, 0), PREF>(img, wq, bias_row(lbias, 2, g), bz);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) { fac0[n] = lrelu_factor16(a0[n]); a0[n] = a0[n] * fac0[n]; }
+        for (int n = 0; n < 3; ++n) { fac0[n] = lrelu_factor16(a0[n]); a0[n] = smul(a0[n], fac0[n]); }
         b0[0] = split_block(a0[0], a0[1]);
         b0[1] = split_block(a0[2], f4{0.f, 0.f, 0.f, 0.f});
         a1[0] = out_tile<L1, 0, pair_of(L1, 1), PREF>(img, wq, bias_row(lbias, 3, g), b0);
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         a1[2] = out_tile<L1, 2, pair_of(L1, 3), PREF>(img, wq, bias_row(lbias, 5, g), b0);
         a1[3] = out_tile<L1, 3, pair_of(L2, 4), PREF>(img, wq, bias_row(lbias, 6, g), b0);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) { fac1[n] = lrelu_factor16(a1[n]); a1[n] = a1[n] * fac1[n]; }
+        for (int n = 0; n < 4; ++n) { fac1[n] = lrelu_factor16(a1[n]); a1[n] = smul(a1[n], fac1[n]); }
         b1[0] = split_block(a1[0], a1[1]);
         b1[1] = split_block(a1[2], a1[3]);
         // the B chain's tiles first: the other chains wait for its quaternions
@@ -413,19 +418,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         by[2] = split_block(gy[4], gy[5]);
         const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f4 d1[4], d0[3], gz[2];
-        d1[0] = out_tile<B2, 0, pair_of(B2, 1), PREF>(img, wq, zero4, by) * fac1[0];
-        d1[1] = out_tile<B2, 1, pair_of(B2, 2), PREF>(img, wq, zero4, by) * fac1[1];
-        d1[2] = out_tile<B2, 2, pair_of(B2, 3), PREF>(img, wq, zero4, by) * fac1[2];
-        d1[3] = out_tile<B2, 3, pair_of(B1, 0), PREF>(img, wq, zero4, by) * fac1[3];
+        d1[0] = smul(out_tile<B2, 0, pair_of(B2, 1), PREF>(img, wq, zero4, by), fac1[0]);
+        d1[1] = smul(out_tile<B2, 1, pair_of(B2, 2), PREF>(img, wq, zero4, by), fac1[1]);
+        d1[2] = smul(out_tile<B2, 2, pair_of(B2, 3), PREF>(img, wq, zero4, by), fac1[2]);
+        d1[3] = smul(out_tile<B2, 3, pair_of(B1, 0), PREF>(img, wq, zero4, by), fac1[3]);
         bd1[0] = split_block(d1[0], d1[1]);
         bd1[1] = split_block(d1[2], d1[3]);
-        d0[0] = out_tile<B1, 0, pair_of(B1, 1), PREF>(img, wq, zero4, bd1) * fac0[0];
-        d0[1] = out_tile<B1, 1, pair_of(B1, 2), PREF>(img, wq, zero4, bd1) * fac0[1];
-        d0[2] = out_tile<B1, 2, pair_of(B0, 0), PREF>(img, wq, zero4, bd1) * fac0[2];
+        d0[0] = smul(out_tile<B1, 0, pair_of(B1, 1), PREF>(img, wq, zero4, bd1), fac0[0]);
+        d0[1] = smul(out_tile<B1, 1, pair_of(B1, 2), PREF>(img, wq, zero4, bd1), fac0[1]);
+        d0[2] = smul(out_tile<B1, 2, pair_of(B0, 0), PREF>(img, wq, zero4, bd1), fac0[2]);
         bd0[0] = split_block(d0[0], d0[1]);
         bd0[1] = split_block(d0[2], zero4);
-        gz[0] = out_tile<B0, 0, pair_of(B0, 1), PREF>(img, wq, zero4, bd0) + a.ctmp * (z[0] - zt[0]);
-        gz[1] = out_tile<B0, 1, pair_of(L0, 0), PREF>(img, wq, zero4, bd0) + a.ctmp * (z[1] - zt[1]); // (the last read is a dummy: the next iteration re-reads it)
+        gz[0] = pull(out_tile<B0, 0, pair_of(B0, 1), PREF>(img, wq, zero4, bd0), a.ctmp, z[0], zt[0]);
+        gz[1] = pull(out_tile<B0, 1, pair_of(L0, 0), PREF>(img, wq, zero4, bd0), a.ctmp, z[1], zt[1]); // (the last read is a dummy: the next iteration re-reads it)
         if (a.dbg && iter == 0 && fvalid) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -434,14 +439,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         // ================= Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
         const float step = adam_t.x, rbc2s = adam_t.y;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            mA[n] = mA[n] + a.one_m_b1 * (gz[n] - mA[n]);
-            vA[n] = vA[n] * a.beta2 + a.one_m_b2 * (gz[n] * gz[n]);
-            const f4 den = f4{__builtin_amdgcn_sqrtf(vA[n].x), __builtin_amdgcn_sqrtf(vA[n].y), __builtin_amdgcn_sqrtf(vA[n].z),
-                              __builtin_amdgcn_sqrtf(vA[n].w)} * rbc2s + a.eps;
-            z[n] = z[n] - step * (mA[n] * f4{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
-                                              __builtin_amdgcn_rcpf(den.w)});
-        }
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // (scalar on purpose: see smul)
+                const float gr = gz[n][r];
+                const float m1 = mA[n][r] + a.one_m_b1 * (gr - mA[n][r]);
+                const float v1 = vA[n][r] * a.beta2 + a.one_m_b2 * (gr * gr);
+                const float den = __builtin_amdgcn_sqrtf(v1) * rbc2s + a.eps;
+                mA[n][r] = m1;
+                vA[n][r] = v1;
+                z[n][r] = z[n][r] - step * (m1 * __builtin_amdgcn_rcpf(den));
+            }
     }
 
     // ================= epilogue: outputs of the LAST forward pass (drag_pose.py:84-113 and what run() returns)
