@@ -113,11 +113,16 @@ DEV f4 mm(u4 a, u4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__b
 // iteration are consumed in a fixed order, so every pair's reads are ISSUED ONE PAIR AHEAD of its six MFMAs (a lone wave otherwise
 // sits out an LDS round trip per pair: 4.8 k of 16 k cycles per iteration waiting at s_waitcnt, profiles/r03_w16_pmc_first.txt).
 struct W3 { u4 h, m, l; };
-template <int PAIR> DEV W3 wload(const u4* img)
+// The image is 135 KB and a ds_read's offset field holds 16 bits: three lane bases 64 KB apart, each opaque to the compiler (it would
+// fold them back into ONE base and pay a v_add_u32 per read beyond the first 64 KB: 71 per iteration).
+struct Img { const u4* b[3]; };
+template <int OFF> DEV u4 img_at(const Img& im) { return im.b[OFF >> 12][OFF & 4095]; } // (OFF in 16-byte units)
+template <int PAIR> DEV W3 wload(const Img& im)
 {
-    const u4* w = img + PAIR * (N_TERMS * 64);
+    constexpr int o = PAIR * (N_TERMS * 64);
+    static_assert(((o + 128) >> 12) < 3, "image beyond the third 64 KB window");
     W3 r;
-    r.h = w[0]; r.m = w[64]; r.l = w[128];
+    r.h = img_at<o>(im); r.m = img_at<o + 64>(im); r.l = img_at<o + 128>(im);
     return r;
 }
 // pins the reads above this point (vector and matrix arithmetic may still move across; LDS operations may not)
@@ -135,7 +140,7 @@ DEV f4 pair_mm(f4 acc, const W3& w, const B3& b)
 }
 // output tile N of product LAYER.  PREF (one wave per SIMD): from weights `w` of its first pair (already in flight); leaves the
 // first pair of NEXT in `w`.  !PREF (two waves per SIMD: the partner covers the LDS latency, and registers are short): read at use.
-template <int LAYER, int N, int NEXT, bool PREF> DEV f4 out_tile(const u4* img, W3& w, f4 acc, const B3* b)
+template <int LAYER, int N, int NEXT, bool PREF> DEV f4 out_tile(const Img& img, W3& w, f4 acc, const B3* b)
 {
     constexpr int P0 = PAIR0[LAYER] + N * NKB[LAYER];
 #pragma unroll
@@ -260,9 +265,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = iter == a.n_iter - 1;
         const f2 adam_t = *(const f2*)((const float*)lds + L16_TAB + 2 * iter);
-        int o = lane;
-        asm volatile("" : "+v"(o)); // opaque per iteration: the weight reads stay inside the loop
-        const u4* img = (const u4*)(lds + L16_IMG) + o;
+        int o0 = lane, o1 = lane + 4096, o2 = lane + 8192;
+        asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2)); // opaque per iteration: the weight reads stay inside the loop
+        const Img img = {{(const u4*)(lds + L16_IMG) + o0, (const u4*)(lds + L16_IMG) + o1, (const u4*)(lds + L16_IMG) + o2}};
         if (last) { zpre[0] = z[0]; zpre[1] = z[1]; }
 
         // ================= forward: a0 = lrelu(A0 z + c0), a1 = lrelu(A1 a0 + b1), y = A2' a1 + b2'

@@ -14,10 +14,10 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 template <class F, int... I> DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-enum { K_FMA, K_MUL, K_ADD, K_SUB, K_AND, K_LSHL, K_CVTPK, K_CNDMASK, K_MOV, K_ACCRD, K_PKMUL, K_PKFMA, K_RSQ, K_MED3, K_BPERM, K_FMAC, K_MULE64, K_PERM32, K_DOT2C, K_DOT2, K_PERMB, K_CVTF32, K_NKINDS };
+enum { K_FMA, K_MUL, K_ADD, K_SUB, K_AND, K_LSHL, K_CVTPK, K_CNDMASK, K_MOV, K_ACCRD, K_PKMUL, K_PKFMA, K_RSQ, K_MED3, K_BPERM, K_FMAC, K_MULE64, K_PERM32, K_DOT2C, K_DOT2, K_PERMB, K_CVTF32, K_PACK, K_ANDOR, K_BFI, K_NKINDS };
 static const char* NAMES[] = {"v_fma_f32", "v_mul_f32_e32", "v_add_f32_e32", "v_sub_f32_e32", "v_and_b32", "v_lshlrev_b32", "v_cvt_pk_bf16_f32", "v_cndmask_b32",
                               "v_mov_b32", "v_accvgpr_read_b32", "v_pk_mul_f32", "v_pk_fma_f32", "v_rsq_f32", "v_med3_f32", "ds_bpermute_b32", "v_fmac_f32_e32",
-                              "v_mul_f32_e64 (neg)", "v_permlane32_swap", "v_dot2c_f32_bf16", "v_dot2_f32_bf16", "v_perm_b32", "v_cvt_f32_bf16"};
+                              "v_mul_f32_e64 (neg)", "v_permlane32_swap", "v_dot2c_f32_bf16", "v_dot2_f32_bf16", "v_perm_b32", "v_cvt_f32_bf16", "v_pack_b32_f16 (hi,hi)", "v_and_or_b32", "v_bfi_b32"};
 struct St { f2 v[8]; unsigned u[8]; f4 a; };
 template <int KIND, int I> DEV void op(St& s, f2 m, f2 c)
 {
@@ -43,6 +43,9 @@ template <int KIND, int I> DEV void op(St& s, f2 m, f2 c)
     if constexpr (KIND == K_DOT2C) asm volatile("v_dot2c_f32_bf16_e32 %0, %1, %2" : "+v"(s.v[i].x) : "v"(0xbf80u), "v"(s.u[i]));
     if constexpr (KIND == K_DOT2) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(s.v[i].x) : "v"(0xbf80u), "v"(s.u[i]));
     if constexpr (KIND == K_PERMB) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s.u[i]) : "v"(s.v[i].x), "v"(s.v[i].y), "v"(0x07060302u));
+    if constexpr (KIND == K_PACK) asm volatile("v_pack_b32_f16 %0, %1, %2 op_sel:[1,1,0]" : "=v"(s.u[i]) : "v"(s.v[i].x), "v"(s.v[i].y));
+    if constexpr (KIND == K_ANDOR) asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(s.u[i]) : "v"(s.v[i].x), "v"(0xffff0000u));
+    if constexpr (KIND == K_BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(s.u[i]) : "v"(0xffff0000u), "v"(s.v[i].x));
     if constexpr (KIND == K_CVTF32) asm volatile("v_cvt_f32_bf16_e32 %0, %1" : "=v"(s.v[i].x) : "v"(s.u[i]));
 }
 DEV void mfma(f4& acc, const s8v& a, const s8v& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
@@ -102,6 +105,18 @@ template <int KIND> __global__ __launch_bounds__(512, 2) void k_pair(float* out,
     if (blockIdx.x == 0 && l == 0) cyc[w] = t1 - t0;
 }
 
+// does v_pack_b32_f16 with op_sel:[1,1,0] pass the two high halves through bit for bit (bf16 patterns are not f16 values)?
+__global__ void k_packbits(unsigned* bad)
+{
+    unsigned n = 0;
+    for (unsigned hi = threadIdx.x + blockIdx.x * blockDim.x; hi < 65536u; hi += blockDim.x * gridDim.x) {
+        const unsigned a = (hi << 16) | 0x1234u, b = ((hi ^ 0x5a5au) << 16) | 0xbeefu;
+        unsigned r;
+        asm volatile("v_pack_b32_f16 %0, %1, %2 op_sel:[1,1,0]" : "=v"(r) : "v"(a), "v"(b));
+        n += r != ((a >> 16) | (b & 0xffff0000u));
+    }
+    if (n) atomicAdd(bad, n);
+}
 static float* out; static unsigned long long* cyc;
 template <int KIND> void run(int iters)
 {
@@ -126,5 +141,9 @@ int main()
 {
     hipMalloc(&out, 1 << 22); hipMalloc(&cyc, 64);
     run_all<0>(200);
+    unsigned* bad; unsigned hb = 0;
+    hipMalloc(&bad, 4); hipMemcpy(bad, &hb, 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_packbits, dim3(64), dim3(256), 0, 0, bad); hipDeviceSynchronize(); hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
+    printf("v_pack_b32_f16 op_sel:[1,1,0]: %u of 65536 high-half patterns (both operands) not passed through bit for bit\n", hb);
     return 0;
 }
