@@ -57,4 +57,9 @@ python3 tools/throughput_sequences.py 3 2>&1 | grep "trackers" >> $O/sequence_th
 python3 tools/seq_timing.py 2>&1 | grep "S =\|steps in" > $O/sequence_step_cost.txt
 python3 tools/plugin_latency.py > $O/plugin_latency.txt 2>&1 || true
 echo "sequences done"
+# 10. the default bench command as the driver runs it (cpu_baseline included), the smoke check and the GPU test log
+python3 bench.py > $O/bench_default.json 2> /dev/null
+python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
+python3 -m pytest tests -q -m gpu -s 2>&1 | grep -v "amdgpu.ids\|Warning\|warnings.warn\|self.encoder" > $O/gpu_tests_log.txt || true
+echo "bench + tests done"
 ls $O
