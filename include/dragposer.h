@@ -13,6 +13,10 @@
  *                            no loss/backward: pose, world root transform and joint positions of z
  *   dp_sequence_advance      the per-frame epilogue of DragPose.run (drag_pose.py:369-402): global pose update,
  *                            joint adjustment, history buffers -- for S sequences in lock-step
+ *   dp_optimize_sequence     the frame loop around both (eval_drag.py:204-222 calling DragPose.run per frame): T consecutive frames
+ *                            of S sequences in one launch, the state carried on the device
+ *   dp_temporal_*            Temporal (temporal_transformer.py:7-77) and the temporal target block of DragPose.run
+ *                            (drag_pose.py:234-294): the source of z_tgt
  *   dp_fold_decoder          host-only helper: the algebra the reference re-does every call
  *                            (W*mask, skeleton.py:120; unpool matmul, skeleton.py:245) done once
  *
