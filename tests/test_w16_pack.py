@@ -117,3 +117,51 @@ def test_image_reconstructs_the_folded_matrices_exactly(wd):
             np.testing.assert_array_equal(sl[k, :3], hm.arrays["offsets"][items[k]])
         else:
             assert not sl[k, :3].any()
+
+
+def _bf16_rne(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32, on bit patterns (what v_cvt_pk_bf16_f32 and the host packer do)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def _split3(x):
+    h = _bf16_rne(x)
+    r1 = (x - h).astype(np.float32)
+    m = _bf16_rne(r1)
+    r2 = (r1 - m).astype(np.float32)
+    return h, m, _bf16_rne(r2)
+
+
+def test_three_bf16_terms_are_exact_and_six_products_reach_fp32_accuracy():
+    """The arithmetic dp_w16 rests on, emulated in numpy: (1) an fp32 number IS the sum of its three round-to-nearest bf16 terms,
+    remainders taken in fp32; (2) a dot product of K = 96 such operands -- the six term products above 2^-24 of the leading one,
+    each exact in fp32 (8 x 8 significant bits), accumulated in fp32 smallest first as the MFMA chain does -- is as close to the
+    fp64 dot product as a plain fp32 dot product is (both within a few 2^-24 of the sum of magnitudes)."""
+    rs = np.random.RandomState(11)
+    x = (rs.standard_normal(1 << 16) * np.exp(rs.uniform(-12, 6, 1 << 16))).astype(np.float32)
+    h, m, l = _split3(x)
+    assert np.array_equal((h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64)).astype(np.float32), x)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))  # exactly
+    K, N = 96, 4096
+    w = (rs.standard_normal((N, K)) * np.exp(rs.uniform(-3, 1, (N, K)))).astype(np.float32)
+    a = (rs.standard_normal((N, K)) * np.exp(rs.uniform(-6, 2, (N, K)))).astype(np.float32)
+    wh, wm, wl = _split3(w)
+    ah, am, al = _split3(a)
+    acc = np.zeros(N, np.float32)
+    for kb in range(K // 32):  # per K-block of 32: the six products, small ones first (dp_w16_impl.h: pair_mm)
+        s = slice(32 * kb, 32 * kb + 32)
+        for p, q in ((wl, ah), (wm, am), (wh, al), (wm, ah), (wh, am), (wh, ah)):
+            prod = p[:, s].astype(np.float64) * q[:, s].astype(np.float64)  # 16 significant bits: exact in fp32 too
+            assert np.array_equal(prod.astype(np.float32).astype(np.float64), prod)
+            for k in range(32):  # (the MFMA's internal order is not specified; any fp32 order obeys the same bound)
+                acc = (acc + prod[:, k].astype(np.float32)).astype(np.float32)
+    exact = (w.astype(np.float64) * a.astype(np.float64)).sum(1)
+    scale = (np.abs(w.astype(np.float64)) * np.abs(a.astype(np.float64))).sum(1)
+    plain = np.zeros(N, np.float32)
+    for k in range(K):
+        plain = (plain + (w[:, k] * a[:, k]).astype(np.float32)).astype(np.float32)
+    e_split, e_plain = np.abs(acc - exact) / scale, np.abs(plain - exact) / scale
+    assert e_split.max() < 16 * 2.0 ** -24 and np.median(e_split) < 2.0 ** -24, (e_split.max(), np.median(e_split))
+    assert e_split.mean() < 1.5 * e_plain.mean(), (e_split.mean(), e_plain.mean())  # (measured: the two are level)
