@@ -889,6 +889,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         return *p;
     };
     int step = 0;
+#ifdef DP_SEQ_STAMPS // diagnostic build (tools/seq_step_stamps.sh): where a step of a whole-sequence launch spends its cycles
+    unsigned long long sq_t[5] = {0, 0, 0, 0, 0}, sq_p = __builtin_amdgcn_s_memtime();
+#define SQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sq_t[i] += n_ - sq_p; sq_p = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SQ_STAMP(i)
+#endif
     do { // (one pass unless SEQ)
     if (SEQ) {
         const KArgs& as = step_args();
@@ -921,6 +927,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             wave_sync();
         }
     }
+    SQ_STAMP(0);
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
         const f2 adam_t = *(const f2*)(lds + L_TAB + 2 * iter); // (an LDS broadcast read, issued a whole iteration ahead of its use)
@@ -1099,6 +1106,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.t[16] = __builtin_amdgcn_s_memrealtime() - rt0; // 100 MHz ticks over the loop
     prof.t[17] = __builtin_amdgcn_s_memtime() - mt0;     // shader cycles over the loop
 #endif
+    SQ_STAMP(1);
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
     const KArgs& ae = step_args();
@@ -1123,6 +1131,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY);
         }
     }
+    SQ_STAMP(2);
     if (optimise && lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
@@ -1134,6 +1143,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         }
     }
     if (optimise && ae.iters && lane < FPW && f0 + lane < nB) ae.iters[row0 + f0 + lane] = EARLY ? es_iters : ae.n_iter;
+    SQ_STAMP(3);
     if (SEQ) { // the rest of run()'s epilogue (drag_pose.py:369-391), one lane per sequence: dp_sequence_advance's arithmetic
         wave_sync();
         if (b == 0) { // (the clamped copies of a ragged tail advance their state too -- or they would fall behind their targets,
@@ -1168,8 +1178,15 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         }
         wave_sync();
     }
+    SQ_STAMP(4);
     ++step;
     } while (SEQ && step < a.seq.n_steps);
+#ifdef DP_SEQ_STAMPS
+    if (SEQ && tid == 0 && blockIdx.x == 0 && a.loss) { // the accumulated stamps over the first floats of `loss`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int k = 0; k < 5; ++k) a.loss[k] = (float)sq_t[k];
+    }
+#endif
 #ifdef DP_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the epilogue's stores have left the wave
     STAMP(11);
