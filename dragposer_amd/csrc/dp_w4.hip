@@ -65,7 +65,9 @@ constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26;     // the streamed product: first g
 constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
 constexpr int L_TAB = L_IMG2 + NG_B2 * 256;     // per-iteration Adam scalars [MAX_ITERS][2]: step, 1/sqrt(1-beta2^t)
 constexpr int L_OC = L_TAB + 2 * MAX_ITERS;     // [16 quads][20] what the epilogue needs per quad: sd[4][2], mu[4][2], path words of both items
-constexpr int L_FR = L_OC + 16 * 20;            // frame blocks [NW * 4][FB_STRIDE]
+constexpr int L_ARGS = L_OC + 16 * 20;          // whole-sequence launches: the fields of the argument block a step reads (StepArgs)
+constexpr int L_ARGS_WORDS = 80;
+constexpr int L_FR = L_ARGS + L_ARGS_WORDS;     // frame blocks [NW * 4][FB_STRIDE]
 template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE; }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,6 +267,14 @@ DEV V3 rot_conj(Q4 q, V3 a)
     return {a.x + 2.f * (c.x - q.w * t.x), a.y + 2.f * (c.y - q.w * t.y), a.z + 2.f * (c.z - q.w * t.z)};
 }
 
+// Pointers that come out of the argument block re-read per step (whole-sequence launches) have lost their address space: the compiler
+// would use FLAT loads and stores, which count against BOTH memory counters -- every later wait for an LDS read then also waits for
+// the results' stores.  Every pointer of the argument block is a device-memory pointer: say so.
+typedef float __attribute__((address_space(1))) gfloat;
+typedef int __attribute__((address_space(1))) gint;
+DEV gfloat* GM(float* p) { return (gfloat*)p; }
+DEV const gfloat* GM(const float* p) { return (const gfloat*)p; }
+DEV gint* GM(int* p) { return (gint*)p; }
 DEV Q4 quat_from_rotmat(const float* m)
 { // row-major 3x3 rotation -> unit quaternion (once per tracker, before the loop).  Shepperd's four branches pick the
   // largest of (w, x, y, z) to divide by; since the result is normalised anyway, each branch is just four sums scaled by a
@@ -281,6 +291,44 @@ DEV Q4 quat_from_rotmat(const float* m)
     q.z = s0 ? c : (s1 ? e : (s2 ? f : 1.f + m22 - m00 - m11));
     const float n = 1.f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     return {q.w * n, q.x * n, q.y * n, q.z * n};
+}
+
+// Whole-sequence launches: what a step reads from the argument block.  Its fields held in scalar registers across the iteration loop
+// would be some 140 of them, spilled; re-read from the kernarg segment per step they come one dependent uncached load at a time (the
+// compiler cannot batch loads it must assume the results' stores may alias: a dozen round trips per step, tools/seq_step_stamps.sh).
+// So the set-up copies them into LDS once and a step reads them from there.
+struct StepArgs {
+    const dpl::ItemConst* items;
+    const float* w4img;
+    const float *z_tgt, *tgt_pos, *tgt_rot, *w;
+    float *z, *z_pre, *pose, *disp, *world_disp, *world_rot, *pos, *rot, *loss;
+    int* iters;
+    int n_iter;
+    float lam_rot, lam_tmp;
+    SeqK seq;
+};
+static_assert(sizeof(StepArgs) <= L_ARGS_WORDS * 4 && alignof(StepArgs) <= 16, "StepArgs fits its LDS slot");
+DEV void stage_step_args(float* lds, const KArgs& a)
+{
+    StepArgs* d = (StepArgs*)(lds + L_ARGS);
+    d->items = a.items; d->w4img = a.w4img;
+    d->z_tgt = a.z_tgt; d->tgt_pos = a.tgt_pos; d->tgt_rot = a.tgt_rot; d->w = a.w;
+    d->z = a.z; d->z_pre = a.z_pre; d->pose = a.pose; d->disp = a.disp; d->world_disp = a.world_disp; d->world_rot = a.world_rot;
+    d->pos = a.pos; d->rot = a.rot; d->loss = a.loss;
+    d->iters = a.iters;
+    d->n_iter = a.n_iter;
+    d->lam_rot = a.lam_rot; d->lam_tmp = a.lam_tmp;
+    d->seq = a.seq;
+}
+template <bool SEQ> DEV decltype(auto) step_args_of(const KArgs& a, const float* lds)
+{
+    if constexpr (SEQ) {
+        int o = L_ARGS;
+        asm volatile("" : "+v"(o)); // opaque per use: the reads stay where a step needs them
+        return *(const StepArgs*)(lds + o);
+    } else {
+        return (a);
+    }
 }
 
 // tracker of rank `rank` of the frame whose tracked-joint mask is `tmask` (E of them), in two halves so that the setup can
@@ -303,7 +351,7 @@ struct TRaw {
     unsigned plo, phi;
     float p[3], wp, wr, m[9];
 };
-DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, int E, int rank, int gf_tgt = -1)
+template <class A> DEV TRaw tracker_fetch(const A& a, bool optimise, int gf, unsigned tmask, int E, int rank, int gf_tgt = -1)
 { // (!optimise: no tracker arrays -- E = 0, every lane inactive; the loads read the weight image instead and are ignored)
   // gf_tgt: row of the targets when it differs from the row of the weights (whole-sequence launches: step * S + sequence)
     TRaw r;
@@ -311,13 +359,16 @@ DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, in
     r.rank = rank;
     const int j = r.act ? nth_set_bit(tmask, rank) : 0;
     r.j = j;
-    r.plo = a.items[j].path_lo;
-    r.phi = a.items[j].path_hi;
+    {
+        const auto* it = (const dpl::ItemConst __attribute__((address_space(1)))*)a.items + j;
+        r.plo = it->path_lo;
+        r.phi = it->path_hi;
+    }
     const int row = optimise ? gf * NJ + j : 0; // (inactive lanes read joint 0's inputs and ignore them)
     const size_t rowt = optimise ? (size_t)(gf_tgt >= 0 ? gf_tgt : gf) * NJ + j : 0;
-    const float* p = (optimise ? a.tgt_pos : a.w4img) + rowt * 3;
-    const float* rm = (optimise ? a.tgt_rot : a.w4img) + rowt * 9;
-    const float* wv = (optimise ? a.w : a.w4img) + (size_t)row * 2;
+    const gfloat* p = GM(optimise ? a.tgt_pos : a.w4img) + rowt * 3;
+    const gfloat* rm = GM(optimise ? a.tgt_rot : a.w4img) + rowt * 9;
+    const gfloat* wv = GM(optimise ? a.w : a.w4img) + (size_t)row * 2;
     r.p[0] = p[0]; r.p[1] = p[1]; r.p[2] = p[2];
     r.wp = wv[0];
     r.wr = wv[1];
@@ -325,7 +376,7 @@ DEV TRaw tracker_fetch(const KArgs& a, bool optimise, int gf, unsigned tmask, in
     for (int k = 0; k < 9; ++k) r.m[k] = rm[k];
     return r;
 }
-DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur, V3 shift = V3{0.f, 0.f, 0.f})
+template <class A> DEV TRec tracker_finish(const A& a, float* fb, const TRaw& r, int E, Q4 cur, V3 shift = V3{0.f, 0.f, 0.f})
 { // shift: added to the position target (whole-sequence launches: tgt_root[t] - current global position)
     TRec t;
     t.act = r.act;
@@ -355,7 +406,7 @@ DEV TRec tracker_finish(const KArgs& a, float* fb, const TRaw& r, int E, Q4 cur,
     }
     return t;
 }
-DEV TRec make_tracker(const KArgs& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur, int gf_tgt = -1, V3 shift = V3{0.f, 0.f, 0.f})
+template <class A> DEV TRec make_tracker(const A& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur, int gf_tgt = -1, V3 shift = V3{0.f, 0.f, 0.f})
 {
     return tracker_finish(a, fb, tracker_fetch(a, true, gf, tmask, E, rank, gf_tgt), E, cur, shift);
 }
@@ -554,8 +605,8 @@ DEV void out_consts(const float* oc, int itemA, int kindA, int itemB, int kindB,
     oA.plo = __float_as_uint(pw.x); oA.phi = __float_as_uint(pw.y);
     oB.plo = __float_as_uint(pw.z); oB.phi = __float_as_uint(pw.w);
 }
-template <bool SEQ = false>
-DEV void w4_outputs(const KArgs& a, const OutC& oc, float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
+template <bool SEQ = false, class A>
+DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
 { // SEQ (whole-sequence launches): gf = step * S + sequence; the state update's inputs are also left in the frame block, and the
   // pose written is the one run() RETURNS (root channels = the normalised world rotation, drag_pose.py:394-396)
     const int item = oc.item, kind = oc.kind;
@@ -567,17 +618,17 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, float* fb, int gf, bool opti
     const Q4 qw = quat_mul(cur, Q4{q0v.x, q0v.y, q0v.z, q0v.w}); // world rotation (drag_pose.py:88)
     const M3 R0 = quat_to_mat(qw);
     if (kind == KIND_DISP) {
-        if (a.disp) { float* o = a.disp + (size_t)gf * 3; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; }
+        if (a.disp) { gfloat* o = GM(a.disp) + (size_t)gf * 3; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; }
         if (a.world_disp || SEQ) {
             const V3 wd = mat_vec(R0, V3{rq.w, rq.x, rq.y});
-            if (a.world_disp) { float* o = a.world_disp + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z; }
+            if (a.world_disp) { gfloat* o = GM(a.world_disp) + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z; }
             if (SEQ) { *(f4*)(fb + FB_SWD) = f4{wd.x, wd.y, wd.z, 0.f}; *(f4*)(fb + FB_SD) = f4{rq.w, rq.x, rq.y, 0.f}; }
         }
         return;
     }
     const Q4 q = rq;
     if (a.pose) {
-        float* o = a.pose + (size_t)gf * 88 + 4 * item;
+        gfloat* o = GM(a.pose) + (size_t)gf * 88 + 4 * item;
         if (SEQ && kind == KIND_ROOT) {
             o[0] = (qw.w - a.seq.mean_q0[0]) / a.seq.std_q0[0]; o[1] = (qw.x - a.seq.mean_q0[1]) / a.seq.std_q0[1];
             o[2] = (qw.y - a.seq.mean_q0[2]) / a.seq.std_q0[2]; o[3] = (qw.z - a.seq.mean_q0[3]) / a.seq.std_q0[3];
@@ -595,22 +646,23 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, float* fb, int gf, bool opti
 #pragma unroll
         for (int k = 0; k < MAX_PATH; ++k) { pr.x += bn[k].x; pr.y += bn[k].y; pr.z += bn[k].z; }
         const V3 pw = mat_vec(R0, pr);
-        if (a.pos) { float* o = a.pos + ((size_t)gf * NJ + item) * 3; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
+        if (a.pos) { gfloat* o = GM(a.pos) + ((size_t)gf * NJ + item) * 3; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
         if (SEQ) { float* o = fb + FB_SPOS + 3 * item; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
     }
     if (a.rot) {
         M3 M = quat_to_mat(q);
         if (kind == KIND_ROOT) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
         const M3 G = mat_mat(R0, M);
-        float* o = a.rot + ((size_t)gf * NJ + item) * 9;
+        gfloat* o = GM(a.rot) + ((size_t)gf * NJ + item) * 9;
         o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
     }
     if (kind == KIND_ROOT) {
-        if (a.world_rot) { float* o = a.world_rot + (size_t)gf * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
+        if (a.world_rot) { gfloat* o = GM(a.world_rot) + (size_t)gf * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
         if (SEQ) *(f4*)(fb + FB_SQW) = f4{qw.w, qw.x, qw.y, qw.z};
         if (optimise && a.loss && early) { // losses of the frame's last executed iteration, as the stop test saw them
             const f4 es = *(const f4*)(fb + FB_ES);
-            a.loss[(size_t)gf * 3 + 0] = es.x; a.loss[(size_t)gf * 3 + 1] = es.y; a.loss[(size_t)gf * 3 + 2] = es.z;
+            gfloat* o = GM(a.loss) + (size_t)gf * 3;
+            o[0] = es.x; o[1] = es.y; o[2] = es.z;
         } else if (optimise && a.loss) {
             float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
             const int E = min(__popc(tmask), W4_R);
@@ -619,9 +671,10 @@ DEV void w4_outputs(const KArgs& a, const OutC& oc, float* fb, int gf, bool opti
                 const f4 dz = *(const f4*)(fb + FB_ZPRE + k) - *(const f4*)(fb + FB_ZT + k);
                 lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
             }
-            a.loss[(size_t)gf * 3 + 0] = lsum_p;
-            a.loss[(size_t)gf * 3 + 1] = lsum_r;
-            a.loss[(size_t)gf * 3 + 2] = lt * a.lam_tmp * (1.f / 24.f);
+            gfloat* o = GM(a.loss) + (size_t)gf * 3;
+            o[0] = lsum_p;
+            o[1] = lsum_r;
+            o[2] = lt * a.lam_tmp * (1.f / 24.f);
         }
     }
 }
@@ -810,6 +863,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #pragma unroll
         for (int k = 0; k < 5; ++k) *(f4*)(lds + L_OC + 20 * b + 4 * k) = ocv[k];
     }
+    if (SEQ && tid == 0) stage_step_args(lds, a);
     if (b == 0) *(f4*)(fb + FB_CUR) = cv;
     wave_sync(); // (the zero fill above and the tracker records below touch the same frame blocks from different lanes)
 
@@ -880,14 +934,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.t[15] = prof.prev - t_setup[2];  // resident weights arrived
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;
 #endif
-    // SEQ: the argument block re-read from the kernarg segment per step through an opaque pointer, so that its fields (some 140
-    // scalar registers' worth) are loaded where a step uses them instead of being held -- and spilled -- across the iteration loop
-    auto step_args = [&]() -> const KArgs& {
-        if (!SEQ) return a;
-        const KArgs* p = (const KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(p));
-        return *p;
-    };
     int step = 0;
 #ifdef DP_SEQ_STAMPS // diagnostic build (tools/seq_step_stamps.sh): where a step of a whole-sequence launch spends its cycles
     unsigned long long sq_t[5] = {0, 0, 0, 0, 0}, sq_p = __builtin_amdgcn_s_memtime();
@@ -897,12 +943,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #endif
     do { // (one pass unless SEQ)
     if (SEQ) {
-        const KArgs& as = step_args();
+        const auto& as = step_args_of<SEQ>(a, lds);
         V3 step_shift = {0.f, 0.f, 0.f};
         int gft = step * nB + gfi;
         asm volatile("" : "+v"(gft)); // (opaque: keeps this step's address arithmetic out of the registers live across the iteration loop)
         if (as.seq.tgt_root) {
-            const float* rp = as.seq.tgt_root + (size_t)gft * 3;
+            const gfloat* rp = GM(as.seq.tgt_root) + (size_t)gft * 3;
             const f4 gpv = *(const f4*)(fb + FB_GPOS);
             step_shift = {rp[0] - gpv.x, rp[1] - gpv.y, rp[2] - gpv.z};
         }
@@ -918,7 +964,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #pragma unroll
                 for (int r = 0; r < FPW; ++r) {
                     const int gf = min(f0 + r, nB - 1);
-                    ztD[r] = as.z_tgt[(size_t)step * as.seq.z_tgt_step + (size_t)gf * as.seq.z_tgt_seq + lane];
+                    ztD[r] = GM(as.z_tgt)[(size_t)step * as.seq.z_tgt_step + (size_t)gf * as.seq.z_tgt_seq + lane];
                     const float dz = zD[r] - ztD[r];
                     fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz;
                 }
@@ -1109,10 +1155,18 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SQ_STAMP(1);
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
-    const KArgs& ae = step_args();
+    const auto& ae = step_args_of<SEQ>(a, lds);
     int row0 = SEQ ? step * nB : 0; // SEQ: this step's slab of the per-step output arrays
     int gfo = row0 + gfi;
-    if (SEQ) { asm volatile("" : "+v"(gfo)); asm volatile("" : "+s"(row0)); } // (opaque, as above)
+    // SEQ: whatever the stores' addresses are made of is opaque per step -- the compiler otherwise hoists the step-invariant 64-bit
+    // parts (item and lane offsets) out of the step loop, holds them across the iteration loop, spills them, and the epilogue then
+    // sits out a dozen scratch reloads one after the other (5 k of a step's 13 k cycles outside the iterations, tools/seq_step_stamps.sh)
+    int lane_e = lane, item_eA = pc.itemA, item_eB = pc.itemB, f0_e = f0, gfi_e = gfi;
+    if (SEQ) {
+        asm volatile("" : "+v"(gfo)); asm volatile("" : "+s"(row0));
+        asm volatile("" : "+v"(lane_e), "+v"(item_eA), "+v"(item_eB), "+v"(gfi_e));
+        asm volatile("" : "+s"(f0_e));
+    }
     if (lane < LAT) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
@@ -1124,7 +1178,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     {
         const f4 cve = *(const f4*)(fb + FB_CUR);
         OutC oA, oB;
-        out_consts(lds + L_OC + 20 * b, pc.itemA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, pc.itemB, pc.kindB, oA, oB);
+        out_consts(lds + L_OC + 20 * b, item_eA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, item_eB, pc.kindB, oA, oB);
         if (fvalid || SEQ) { // (SEQ: the clamped copies of a ragged tail keep their own state consistent; their stores are skipped below)
             const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
             w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY); // (SEQ: the copies re-store the last valid frame's rows, same values)
@@ -1136,13 +1190,13 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
             if (f0 + r < nB) {
-                if (ae.z && (!SEQ || step == ae.seq.n_steps - 1)) ae.z[(size_t)(f0 + r) * LAT + lane] = EARLY ? zfinD[r] : zD[r];
-                if (ae.z_pre) ae.z_pre[(size_t)(row0 + f0 + r) * LAT + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
-                if (SEQ) ae.seq.hist[(size_t)(row0 + f0 + r) * (LAT + 3 + ae.seq.n_heights) + lane] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
+                if (ae.z && (!SEQ || step == ae.seq.n_steps - 1)) GM(ae.z)[(size_t)(f0_e + r) * LAT + lane_e] = EARLY ? zfinD[r] : zD[r];
+                if (ae.z_pre) GM(ae.z_pre)[(size_t)(row0 + f0_e + r) * LAT + lane_e] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
+                if (SEQ) GM(ae.seq.hist)[(size_t)(row0 + f0_e + r) * (LAT + 3 + ae.seq.n_heights) + lane_e] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
             }
         }
     }
-    if (optimise && ae.iters && lane < FPW && f0 + lane < nB) ae.iters[row0 + f0 + lane] = EARLY ? es_iters : ae.n_iter;
+    if (optimise && ae.iters && lane < FPW && f0 + lane < nB) GM(ae.iters)[row0 + f0_e + lane_e] = EARLY ? es_iters : ae.n_iter;
     SQ_STAMP(3);
     if (SEQ) { // the rest of run()'s epilogue (drag_pose.py:369-391), one lane per sequence: dp_sequence_advance's arithmetic
         wave_sync();
@@ -1153,9 +1207,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             float gp[3] = {gp0.x + wd.x, gp0.y + wd.y, gp0.z + wd.z}; // drag_pose.py:370
             float dsp[3] = {ds.x, ds.y, ds.z};
             if (ae.seq.adjust_joint >= 0) { // drag_pose.py:374-381
-                const float* tpp = ae.tgt_pos + ((size_t)gfo * NJ + ae.seq.adjust_target_joint) * 3;
+                const gfloat* tpp = GM(ae.tgt_pos) + ((size_t)gfo * NJ + ae.seq.adjust_target_joint) * 3;
                 float sh[3] = {0.f, 0.f, 0.f}; // this step's target shift again (tgt_root[t] - the global position BEFORE this step)
-                if (ae.seq.tgt_root) { const float* rp = ae.seq.tgt_root + (size_t)gfo * 3; sh[0] = rp[0] - gp0.x; sh[1] = rp[1] - gp0.y; sh[2] = rp[2] - gp0.z; }
+                if (ae.seq.tgt_root) { const gfloat* rp = GM(ae.seq.tgt_root) + (size_t)gfo * 3; sh[0] = rp[0] - gp0.x; sh[1] = rp[1] - gp0.y; sh[2] = rp[2] - gp0.z; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float adj = ((tpp[k] + sh[k]) - fb[FB_SPOS + 3 * ae.seq.adjust_joint + k]) * ae.seq.adjust_weight;
@@ -1163,17 +1217,17 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                     dsp[k] += adj;
                 }
             }
-            if (ae.seq.pos_ret && fvalid) { float* o = ae.seq.pos_ret + (size_t)gfo * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; }
+            if (ae.seq.pos_ret && fvalid) { gfloat* o = GM(ae.seq.pos_ret) + (size_t)gfo * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; }
             if (fvalid) {
-                float* o = ae.seq.hist + (size_t)gfo * (LAT + 3 + ae.seq.n_heights) + LAT;
+                gfloat* o = GM(ae.seq.hist) + (size_t)gfo * (LAT + 3 + ae.seq.n_heights) + LAT;
                 o[0] = dsp[0]; o[1] = dsp[1]; o[2] = dsp[2];
                 for (int h = 0; h < ae.seq.n_heights; ++h) o[3 + h] = fb[FB_SPOS + 3 * ae.seq.height_joints[h] + 1] + gp[1];
             }
             *(f4*)(fb + FB_GPOS) = f4{gp[0], gp[1], gp[2], 0.f};
             *(f4*)(fb + FB_CUR) = qw; // drag_pose.py:371
             if (step == ae.seq.n_steps - 1 && fvalid) {
-                float* o = ae.seq.global_pos + (size_t)gfi * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
-                *(f4*)(ae.seq.global_rot + (size_t)gfi * 4) = qw;
+                gfloat* o = GM(ae.seq.global_pos) + (size_t)gfi_e * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
+                gfloat* oq = GM(ae.seq.global_rot) + (size_t)gfi_e * 4; oq[0] = qw.x; oq[1] = qw.y; oq[2] = qw.z; oq[3] = qw.w;
             }
         }
         wave_sync();
