@@ -28,6 +28,8 @@ for S in (1, 4, 64, 1024):
         torch.cuda.synchronize()
         res.append((n_iter, (time.time() - t0) / T * 1e6))
     per_iter = (res[-1][1] - res[0][1]) / (res[-1][0] - res[0][0])
+    if S == 1:
+        fixed_s1 = res[0][1] - per_iter
     print(f"S = {S:5d}: " + ", ".join(f"{n} it: {us:.1f} us/step" for n, us in res) + f" -> {per_iter:.2f} us per iteration, {res[0][1] - per_iter:.1f} us per step besides")
 
 # long single-sequence runs: fixed count, then the reference's early-stop settings on fresh targets every step
@@ -52,4 +54,4 @@ for label, kw, same in (("fixed 8 iterations, same targets", dict(n_iter=8, stop
         torch.cuda.synchronize()
         dt = time.time() - t0
     it = r["iters"].float().mean().item()
-    print(f"{label}: {T} steps in {dt * 1e3:.1f} ms = {dt / T * 1e6:.1f} us/step, mean iterations {it:.1f} -> {(dt / T * 1e6 - 6.0) / it:.2f} us per iteration after 6 us per step")
+    print(f"{label}: {T} steps in {dt * 1e3:.1f} ms = {dt / T * 1e6:.1f} us/step, mean iterations {it:.1f} -> {(dt / T * 1e6 - fixed_s1) / it:.2f} us per iteration after the {fixed_s1:.1f} us per step measured above")
