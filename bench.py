@@ -233,7 +233,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.total_frames > 0 else "weak",
             "vs_baseline": None,
-            "dtype": ("bf16 weights (three bf16 terms per folded fp32 entry) x fp32 activations (three bf16 terms), fp32 accumulate" if fpb >= 64 else "f32"),
+            # dp_w16: every fp32 operand as the exact sum of three bf16 terms, six term products per block on the bf16 MFMA, fp32 accumulate
+            "dtype": ((("bf16-rounded weights" if s4 else "f32 weights") + " and f32 activations, each as three bf16 terms on the bf16 MFMA (f32-equivalent), f32 accumulate")
+                      if fpb >= 64 else ("f32 (bf16-rounded weights)" if s4 else "f32")),
             "data": "synthetic",
             "config": {"workload": ((f"{'S4' if s4 else 'S1'}: ONE batch of {total_per_step} synthetic frames" if args.total_frames > 0 else
                                      f"{'S4' if s4 else 'S1'}: {B} synthetic frames per GPU") +

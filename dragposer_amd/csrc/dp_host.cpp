@@ -637,7 +637,7 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: unknown kernel selector");
     if (p->kernel == DP_KERNEL_W16 && !w16_can)
         return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 runs a fixed iteration count on the reference's 22-joint skeleton only");
-    const int kernel = p->kernel == DP_KERNEL_W16 || (p->kernel == DP_KERNEL_AUTO && w16_can && in->n_frames >= 8192)
+    const int kernel = p->kernel == DP_KERNEL_W16 || (p->kernel == DP_KERNEL_AUTO && w16_can && in->n_frames > ctx->n_cu * 16 /* more than one round of dp_w4's 16 frames per CU */)
                            ? DP_KERNEL_W16 : DP_KERNEL_W4;
     return launch(ctx, k, stream, kernel);
 }

@@ -128,8 +128,9 @@ typedef struct dp_params {
  *   DP_KERNEL_W4   4 frames per wavefront, fp32 MFMA (v_mfma_f32_4x4x1): every launch shape, early stop, forward-only.
  *   DP_KERNEL_W16  16 frames per wavefront, decoder on v_mfma_f32_16x16x32_bf16 in split precision (every fp32 operand the
  *                  exact sum of three bf16 terms, six term products per block accumulated in fp32): fixed iteration count
- *                  only, the reference's 22-joint skeleton only; DP_ERR_UNSUPPORTED otherwise.  Pays from ~8192 frames.
- *   DP_KERNEL_AUTO W16 from 8192 frames without early stop (either weight type: both kernels compute in fp32-equivalent
+ *                  only, the reference's 22-joint skeleton only; DP_ERR_UNSUPPORTED otherwise.  Pays as soon as W4 needs a second round (it holds 16 frames
+ *                  per CU at a time: 4096 on an MI355X).
+ *   DP_KERNEL_AUTO W16 for more than 16 frames per CU (> 4096 on an MI355X) without early stop (either weight type: both kernels compute in fp32-equivalent
  *                  arithmetic and are held to the same reference run, tests/test_hip_parity.py::test_full_size_batch_properties),
  *                  W4 otherwise -- BASELINE's 1024- and 4096-frame batches, every early-stop and sequence launch. */
 #define DP_KERNEL_AUTO 0

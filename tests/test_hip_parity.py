@@ -211,7 +211,7 @@ def test_full_size_batch_properties(opt, dev, golden_dir, kernel):
     """BASELINE's headline batch (4096 frames x 50 iterations): determinism, batch-position invariance, and parity on EVERY
     frame against the REAL reference's fp32 run of the same inputs (tests/golden/full4096.npz: the reference's DragPose.run,
     frame by frame, in fp32 and in fp64).  "auto" is dp_w4 at this size; "w16" holds the large-batch kernel (split-bf16
-    products, what "auto" launches from 8192 frames) to the same reference run and the same bar."""
+    products, what "auto" launches beyond 4096 frames) to the same reference run and the same bar."""
     from dragposer_amd.optimizer import to_device_batch
 
     m = R.OracleModel()

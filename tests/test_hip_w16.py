@@ -113,7 +113,7 @@ def test_large_mixed_batch_agrees_with_the_fp32_mfma_kernel(opts, dev):
     m = R.OracleModel(weight_rounding="bf16")
     b = R.synth_inputs(m, 16384, mixed=True)
     d = to_device_batch(b, dev)
-    a16 = _run(opts["bf16"], d, n_iter=50, kernel="auto")  # bf16 context, >= 8192 frames, fixed count: w16
+    a16 = _run(opts["bf16"], d, n_iter=50, kernel="auto")  # more than one round of dp_w4, fixed count: w16
     assert opts["bf16"].kernel_geometry()[:2] == (64, 256)  # 16384 frames = one wave per SIMD
     a4 = _run(opts["bf16"], d, n_iter=50, kernel="w4")
     assert opts["bf16"].kernel_geometry()[0] == 16

@@ -19,8 +19,8 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "S
 done
 python3 tools/pmc_summary.py $O/pmc_per_launch.json $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 $O/pmc6 $O/pmc7 > /dev/null
 # 3. batch sweep
-# (the library's own kernel choice: dp_w4 up to 4096 frames, dp_w16 from 8192; then dp_w4 forced at the large sizes for comparison)
-for spec in 256:auto 1024:auto 2048:auto 4096:auto 8192:auto 16384:auto 65536:auto 8192:w4 16384:w4 65536:w4; do
+# (the library's own kernel choice: dp_w4 up to 4096 frames, dp_w16 beyond; then dp_w4 forced at the large sizes for comparison)
+for spec in 256:auto 1024:auto 2048:auto 4096:auto 6144:auto 8192:auto 16384:auto 65536:auto 6144:w4 8192:w4 16384:w4 65536:w4; do
   fr=${spec%%:*}; kn=${spec##*:}
   python3 bench.py --frames $fr --kernel $kn --steps 20 --warmup 3 --no-cpu-baseline --no-parity | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '--kernel $kn:', '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
 done > $O/batch_sweep.txt
@@ -47,7 +47,7 @@ python3 bench.py --config s4 --frames 16384 --steps 20 --warmup 3 --no-cpu-basel
 python3 bench.py --config s4 --frames 65536 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_s4_65536.json 2> /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/s4stats --output-format csv -- python3 bench.py --config s4 --frames 16384 --steps 20 --no-cpu-baseline > $O/bench_s4_under_rocprof.json 2> $O/s4stats.log
 grep "dp_w16_kernel\|dp_w4_kernel\|\"Name\"" $(find $O/s4stats -name "*kernel_stats.csv" | head -1) > $O/bench_s4_kernel_stats.csv
-python3 tools/w16_sweep.py 4096 8192 16384 32768 65536 131072 > $O/w16_sweep.txt 2>&1
+python3 tools/w16_sweep.py 4096 5120 6144 8192 16384 32768 65536 131072 > $O/w16_sweep.txt 2>&1
 bash tools/w16_pmc.sh 16384 $O/w16_pmc_16384 > $O/w16_pmc_16384.txt 2>&1
 bash tools/w16_pmc.sh 65536 $O/w16_pmc_65536 > $O/w16_pmc_65536.txt 2>&1
 echo "w16 done"

@@ -22,7 +22,7 @@ for wd in ("bf16", "fp32"):  # throw-away launches: the first timed loop of a pr
 torch.cuda.synchronize()
 for wd in ("bf16", "fp32"):
     for B in sizes:
-        b = {k: np.concatenate([v] * (B // 4096)) if B >= 4096 else v[:B] for k, v in base[wd].items()}
+        b = {k: np.concatenate([v] * ((B + 4095) // 4096))[:B] for k, v in base[wd].items()}
         d = to_device_batch(b, dev)
         row = []
         for kern in ("w4", "w16"):
