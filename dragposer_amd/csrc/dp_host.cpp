@@ -632,11 +632,11 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
     }
     // which kernel (include/dragposer.h: DP_KERNEL_*)
-    const bool w16_can = ctx->d_w16img != nullptr && !k.early_stop;
+    const bool w16_can = ctx->d_w16img != nullptr;
     if (p->kernel != DP_KERNEL_AUTO && p->kernel != DP_KERNEL_W4 && p->kernel != DP_KERNEL_W16)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: unknown kernel selector");
     if (p->kernel == DP_KERNEL_W16 && !w16_can)
-        return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 runs a fixed iteration count on the reference's 22-joint skeleton only");
+        return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 is laid out for the reference's 22-joint skeleton only");
     const int kernel = p->kernel == DP_KERNEL_W16 || (p->kernel == DP_KERNEL_AUTO && w16_can && in->n_frames > ctx->n_cu * 16 /* more than one round of dp_w4's 16 frames per CU */)
                            ? DP_KERNEL_W16 : DP_KERNEL_W4;
     return launch(ctx, k, stream, kernel);

@@ -7,8 +7,12 @@ extern "C" hipError_t dp_launch_w16_2w(const KArgs* args, hipStream_t stream);
 
 // One wave per SIMD (4 waves, 64 frames per workgroup) until every SIMD of the chip has a wave; beyond that two waves per SIMD
 // (8 waves, 128 frames per workgroup): the matrix phases of one wave run under the vector phases of the other.
+extern "C" hipError_t dp_launch_w16_es(const KArgs* args, hipStream_t stream);
+extern "C" hipError_t dp_launch_w16_2w_es(const KArgs* args, hipStream_t stream);
+
 extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int waves)
 {
+    if (args->early_stop) return waves == 8 ? dp_launch_w16_2w_es(args, stream) : dp_launch_w16_es(args, stream);
     if (waves == 8) return dp_launch_w16_2w(args, stream);
     const int grid = (args->n_frames + 4 * FPW - 1) / (4 * FPW);
     hipLaunchKernelGGL((dp_w16_kernel<4, 1>), dim3(grid), dim3(256), 0, stream, *args);

@@ -176,7 +176,11 @@ DEV f4 bias_row(const float* lds_bias, int tile, int g) { return *(const f4*)(ld
 
 // ------------------------------------------------------------------------------------------------
 // NW waves per workgroup, WPS waves per SIMD (register budget 512 / WPS): one workgroup per CU either way (the LDS image).
-template <int NW, int WPS>
+// EARLY: the reference's per-frame while-condition (drag_pose.py:298-304, 351-355), as dp_w4.hip runs it: a frame whose condition fails
+// takes this one last step (its final latent) and then keeps its pre-step latent, so that the forward passes it still takes part in
+// reproduce its last one; a wave leaves the loop once all sixteen of its frames have stopped.  A frame is a lane column here, its
+// state replicated over the four lane groups.
+template <int NW, int WPS, bool EARLY = false>
 __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[L16_END];
@@ -261,6 +265,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     V3 dsp = {0.f, 0.f, 0.f};
     f4 zpre[2] = {z[0], z[1]};
     float loss_p = 0.f, loss_r = 0.f;
+    // EARLY: total loss of the frame's previous iteration, still iterating, iterations executed, losses of its last executed
+    // iteration (pos, rot, tmp), latent after its last step
+    float es_prev = 10000000.f, es_lp = 0.f, es_lr = 0.f, es_lt = 0.f;
+    bool es_act = true;
+    int es_iters = 0;
+    f4 zfin[2] = {z[0], z[1]};
 
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = iter == a.n_iter - 1;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         int o0 = lane, o1 = lane + 4096, o2 = lane + 8192;
         asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2)); // opaque per iteration: the weight reads stay inside the loop
         const Img img = {{(const u4*)(lds + L16_IMG) + o0, (const u4*)(lds + L16_IMG) + o1, (const u4*)(lds + L16_IMG) + o2}};
-        if (last) { zpre[0] = z[0]; zpre[1] = z[1]; }
+        if (!EARLY && last) { zpre[0] = z[0]; zpre[1] = z[1]; }
 
         // ================= forward: a0 = lrelu(A0 z + c0), a1 = lrelu(A1 a0 + b1), y = A2' a1 + b2'
         f4 fac0[3], fac1[4], y[NTY];
@@ -358,13 +368,29 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
                 RT = RT + cross3(at, gp[t]) + ow;
                 GD = GD + gp[t];
                 own[t] = t == 4 ? sel3(is_root, zero3, ow) : ow; // (the root's own torque is part of the root sum only)
-                if (last) {
+                if (EARLY || last) {
                     lp += 0.5f * cgp[t] * dot3(e, e);
                     lr -= k8[t] * (s.x * s.x + s.y * s.y + s.z * s.z);
                 }
             }
         }
-        if (last) { loss_p = lp; loss_r = lr; }
+        if (!EARLY && last) { loss_p = lp; loss_r = lr; }
+        bool was_act = true, stop_now = false;
+        if (EARLY) { // the stop test of my frame, in all four of its lanes
+            const float sp = sum_groups(lp), sr = sum_groups(lr);
+            float l2 = 0.f;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { const f4 dz = z[n] - zt[n]; l2 += (dz.x * dz.x + dz.y * dz.y) + (dz.z * dz.z + dz.w * dz.w); }
+            const float st = sum_groups(l2) * (a.lam_tmp * (1.f / 24.f));
+            const float tot = (sp + sr) + st;
+            const bool cont = (sp > a.stop_eps_pos || sr > a.stop_eps_rot) && (es_prev - tot > a.min_loss_incr) && !last;
+            was_act = es_act;
+            es_prev = es_act ? tot : es_prev;
+            es_iters += es_act ? 1 : 0;
+            es_lp = es_act ? sp : es_lp; es_lr = es_act ? sr : es_lr; es_lt = es_act ? st : es_lt;
+            stop_now = es_act && !cont;
+            es_act = es_act && cont;
+        }
 
         // ================= stage G: subtree sums up the chains, torques, dL/dq, dL/dy
         RT = sum_groups3(RT);
@@ -451,18 +477,34 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
                 const float m1 = mA[n][r] + a.one_m_b1 * (gr - mA[n][r]);
                 const float v1 = vA[n][r] * a.beta2 + a.one_m_b2 * (gr * gr);
                 const float den = __builtin_amdgcn_sqrtf(v1) * rbc2s + a.eps;
-                mA[n][r] = m1;
-                vA[n][r] = v1;
-                z[n][r] = z[n][r] - step * (m1 * __builtin_amdgcn_rcpf(den));
+                const float z1 = z[n][r] - step * (m1 * __builtin_amdgcn_rcpf(den));
+                if (!EARLY) {
+                    mA[n][r] = m1;
+                    vA[n][r] = v1;
+                    z[n][r] = z1;
+                } else { // a frame that stops now: this step gives its final latent, z / m / v stay; a stopped frame: nothing moves
+                    const bool go = was_act && !stop_now;
+                    zpre[n][r] = stop_now ? z[n][r] : zpre[n][r]; // latent of the frame's LAST forward pass
+                    zfin[n][r] = stop_now ? z1 : zfin[n][r];
+                    mA[n][r] = go ? m1 : mA[n][r];
+                    vA[n][r] = go ? v1 : vA[n][r];
+                    z[n][r] = go ? z1 : z[n][r];
+                }
             }
+        if (EARLY && __ballot(es_act) == 0ull) break; // every frame of the wave has stopped
     }
 
     // ================= epilogue: outputs of the LAST forward pass (drag_pose.py:84-113 and what run() returns)
-    const float lsum_p = sum_groups(loss_p), lsum_r = sum_groups(loss_r);
-    float lt = 0.f;
+    float lsum_p, lsum_r, lt;
+    if (EARLY) { // the losses of the frame's last executed iteration, as its stop test saw them
+        lsum_p = es_lp; lsum_r = es_lr; lt = es_lt;
+    } else {
+        lsum_p = sum_groups(loss_p); lsum_r = sum_groups(loss_r);
+        lt = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) { const f4 dz = zpre[n] - zt[n]; lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w; }
-    lt = sum_groups(lt) * a.lam_tmp * (1.f / 24.f);
+        for (int n = 0; n < 2; ++n) { const f4 dz = zpre[n] - zt[n]; lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w; }
+        lt = sum_groups(lt) * a.lam_tmp * (1.f / 24.f);
+    }
     if (!fvalid) return;
     const Q4 qw = quat_mul(cur, q0); // world rotation (drag_pose.py:88)
     const M3 R0 = quat_to_mat(qw);
@@ -470,7 +512,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     for (int n = 0; n < 2; ++n) {
         const int c = 16 * n + 4 * g;
         if (c < LAT) {
-            if (a.z) *(f4*)(a.z + (size_t)gf * LAT + c) = z[n];
+            if (a.z) *(f4*)(a.z + (size_t)gf * LAT + c) = EARLY ? zfin[n] : z[n];
             if (a.z_pre) *(f4*)(a.z_pre + (size_t)gf * LAT + c) = zpre[n];
         }
     }
@@ -495,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
             if (item == 0) {
                 if (a.world_rot) *(f4*)(a.world_rot + (size_t)gf * 4) = f4{qw.w, qw.x, qw.y, qw.z};
                 if (a.loss) { float* o = a.loss + (size_t)gf * 3; o[0] = lsum_p; o[1] = lsum_r; o[2] = lt; }
-                if (a.iters) a.iters[gf] = a.n_iter;
+                if (a.iters) a.iters[gf] = EARLY ? es_iters : a.n_iter;
             }
         }
     }

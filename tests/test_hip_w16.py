@@ -162,8 +162,7 @@ def test_any_joint_may_carry_a_tracker(opts, dev, n_trk):
     np.testing.assert_allclose(o["loss"][~sens], o32["loss"][~sens], rtol=2e-3, atol=1e-8)
 
 
-def test_untracked_frame_and_unsupported_modes(opts, dev, golden_dir):
-    from dragposer_amd import _lib
+def test_untracked_frame_only_feels_the_temporal_pull(opts, dev, golden_dir):
     from dragposer_amd.optimizer import to_device_batch
 
     g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
@@ -174,6 +173,62 @@ def test_untracked_frame_and_unsupported_modes(opts, dev, golden_dir):
     assert np.isfinite(o["z"]).all() and np.isfinite(o["pos"]).all()
     assert np.abs(o["z"][3] - b["z_tgt"][3]).max() < np.abs(b["z0"][3] - b["z_tgt"][3]).max()  # only the temporal pull acts
     assert o["loss"][3, 0] == 0 and o["loss"][3, 1] == 0
-    with pytest.raises(_lib.DragPoserError) as e:  # the per-frame while-condition stays with the 4-frames-per-wave kernel
-        opts["none"].optimize(**to_device_batch(b, dev), n_iter=30, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5, kernel="w16")
-    assert e.value.code == _lib.DP_ERR_UNSUPPORTED
+
+
+def test_early_stop_matches_reference_loop(opts, dev, golden_dir):
+    """The reference's own eval settings (eval_drag.py:210-214) through the 16-frames-per-wave kernel: iteration counts, returned
+    pose and stepped latent per frame against the reference's recorded run (golden `es`), the bar of tests/test_hip_parity.py's
+    test for dp_w4; a frame's count and result do not depend on which frames share its wave; and the two kernels agree."""
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, "es.npz"))
+    mt = g["meta"]
+    kw = dict(n_iter=mt["n_iter"], lambda_tmp=mt["lambda_tmp"], stop_eps_pos=mt["stop_eps_pos"], stop_eps_rot=mt["stop_eps_rot"],
+              min_loss_incr=mt["min_loss_incr"])
+    o = _run(opts["none"], to_device_batch(g, dev), kernel="w16", **kw)
+    assert opts["none"].kernel_geometry()[0] == 64
+    same = o["iters"] == g["iters"]
+    print(f"early stop, dp_w16 vs the reference: {same.mean():.3f} of the frames with the same iteration count, max difference {np.abs(o['iters'] - g['iters']).max()}, "
+          f"positions {_mm(o['pos'][same], g['pos'][same]).max():.4f} mm")
+    assert same.mean() >= 0.95 and np.abs(o["iters"] - g["iters"]).max() <= 1, (same.mean(), np.abs(o["iters"] - g["iters"]).max())
+    assert _mm(o["pos"][same], g["pos"][same]).max() <= 0.05
+    np.testing.assert_allclose(o["z"][same], g["z_final"][same], atol=5e-5)
+    np.testing.assert_allclose(o["z_pre"][same], g["z_pre"][same], atol=5e-5)
+    last = g["loss_hist"][np.arange(len(g["iters"])), g["iters"] - 1]
+    np.testing.assert_allclose(o["loss"][same], last[same], rtol=2e-3, atol=1e-8)
+    perm = np.random.RandomState(1).permutation(len(g["z0"]))
+    shuf = _run(opts["none"], to_device_batch({k: g[k][perm] for k in KEYS}, dev), kernel="w16", **kw)
+    for k in ("z", "z_pre", "pos", "loss", "iters"):
+        np.testing.assert_array_equal(shuf[k], o[k][perm], err_msg=k)
+    one = _run(opts["none"], to_device_batch({k: g[k][5:6] for k in KEYS}, dev), kernel="w16", **kw)
+    for k in ("z", "pos", "iters"):
+        np.testing.assert_array_equal(one[k][0], o[k][5], err_msg=k)
+    w4 = _run(opts["none"], to_device_batch(g, dev), kernel="w4", **kw)
+    both = o["iters"] == w4["iters"]
+    assert both.mean() >= 0.95 and np.abs(o["iters"] - w4["iters"]).max() <= 1
+    assert _mm(o["pos"][both], w4["pos"][both]).max() <= 0.05
+
+
+def test_early_stop_at_size_and_kernel_choice(opts, dev):
+    """more than one round of dp_w4 with the while-condition: the library launches dp_w16 (two waves per SIMD beyond 16 384 frames);
+    against dp_w4 frame by frame -- iteration counts equal on all but the frames whose loss increment sits within rounding of the
+    threshold, positions within 0.05 mm where the counts agree (kink frames counted as everywhere else)"""
+    from dragposer_amd.optimizer import to_device_batch
+
+    m = R.OracleModel()
+    kw = dict(n_iter=60, lambda_tmp=0.02, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5)
+    for B, fpw in ((8192, 64), (20480, 128)):
+        d = to_device_batch(R.synth_inputs(m, B, seed=9), dev)
+        a = _run(opts["none"], d, kernel="auto", **kw)
+        assert opts["none"].kernel_geometry()[0] == fpw, opts["none"].kernel_geometry()
+        w4 = _run(opts["none"], d, kernel="w4", **kw)
+        assert opts["none"].kernel_geometry()[0] == 16
+        same = a["iters"] == w4["iters"]
+        e = _mm(a["pos"][same], w4["pos"][same]).max(axis=1)
+        print(f"B={B}: iteration counts equal on {same.mean():.4f} of the frames (mean {a['iters'].mean():.1f}, range {a['iters'].min()}..{a['iters'].max()}), "
+              f"max difference {np.abs(a['iters'] - w4['iters']).max()}; where equal: positions max {e.max():.3f} mm, above 0.05 mm: {(e > 0.05).sum()}")
+        assert same.mean() >= 0.97 and a["iters"].min() < a["iters"].max()
+        assert (e > 0.05).sum() <= max(2, B // 1000) and np.percentile(e, 99.8) <= 0.05
+        again = _run(opts["none"], d, kernel="auto", **kw)
+        for k in a:
+            np.testing.assert_array_equal(a[k], again[k])  # bitwise reproducible
