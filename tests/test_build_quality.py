@@ -18,6 +18,10 @@ pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hip
 def _kernel_notes(src, tmp_path):
     out = tmp_path / (src + ".s")
     flags = [f for f in G.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    if src in G.SCHED_OVERRIDE:  # the per-source flags of __graft_entry__._compile_objects
+        i = flags.index("-amdgpu-sched-strategy=max-ilp")
+        flags[i - 1:i + 1] = ["-mllvm", "-amdgpu-sched-strategy=" + G.SCHED_OVERRIDE[src]] if G.SCHED_OVERRIDE[src] else []
+    flags += G.EXTRA_FLAGS.get(src, [])
     subprocess.check_call(["hipcc", *flags, "-S", "--cuda-device-only", "-o", str(out), os.path.join(G.CSRC, src)],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
@@ -72,3 +76,20 @@ def test_temporal_kernel_variants_fit_their_occupancy(tmp_path):
         assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
         assert n["lds"] <= 80 * 1024, (name, n)      # two workgroups per CU
     assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, True, True]  # the 2-waves-per-SIMD variant uses the full file
+
+
+@pytest.mark.parametrize("src, one_wave", [("dp_w16.hip", True), ("dp_w16_es.hip", True), ("dp_w16_2w.hip", False), ("dp_w16_2w_es.hip", False)])
+def test_w16_instantiations_keep_their_register_budget(tmp_path, src, one_wave):
+    """the 16-frames-per-wave kernel, each instantiation with its own flags: one wave per SIMD has the whole register file and must
+    not spill; two waves per SIMD run in 256 registers with a bounded spill (latency the partner wave covers); no packed fp32
+    instruction anywhere (it would stall for a bf16 MFMA in flight: DESIGN.md 6.4); the 135 KB weight image plus tables in LDS"""
+    out = tmp_path / (src + ".s")
+    notes = _kernel_notes(src, tmp_path)
+    (name, n), = [(k, v) for k, v in notes.items() if "dp_w16_kernel" in k]
+    assert 135 * 1024 <= n["lds"] <= 160 * 1024, (name, n)
+    if one_wave:
+        assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
+    else:
+        assert n["vgpr"] <= 256 and n["vspill"] <= 72, (name, n)
+    text = out.read_text()
+    assert "v_pk_fma_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text
