@@ -217,18 +217,19 @@ def test_early_stop_at_size_and_kernel_choice(opts, dev):
 
     m = R.OracleModel()
     kw = dict(n_iter=60, lambda_tmp=0.02, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5)
-    for B, fpw in ((8192, 64), (20480, 128)):
-        d = to_device_batch(R.synth_inputs(m, B, seed=9), dev)
-        a = _run(opts["none"], d, kernel="auto", **kw)
-        assert opts["none"].kernel_geometry()[0] == fpw, opts["none"].kernel_geometry()
-        w4 = _run(opts["none"], d, kernel="w4", **kw)
-        assert opts["none"].kernel_geometry()[0] == 16
+    for B, fpw, wd in ((8192, 64, "none"), (20480, 128, "none"), (8192, 64, "bf16")):  # (bf16: BASELINE config 5's mixed tracker counts)
+        o = opts[wd]
+        d = to_device_batch(R.synth_inputs(R.OracleModel(weight_rounding=wd), B, seed=9, mixed=(wd == "bf16")), dev)
+        a = _run(o, d, kernel="auto", **kw)
+        assert o.kernel_geometry()[0] == fpw, o.kernel_geometry()
+        w4 = _run(o, d, kernel="w4", **kw)
+        assert o.kernel_geometry()[0] == 16
         same = a["iters"] == w4["iters"]
         e = _mm(a["pos"][same], w4["pos"][same]).max(axis=1)
-        print(f"B={B}: iteration counts equal on {same.mean():.4f} of the frames (mean {a['iters'].mean():.1f}, range {a['iters'].min()}..{a['iters'].max()}), "
+        print(f"B={B} ({wd}): iteration counts equal on {same.mean():.4f} of the frames (mean {a['iters'].mean():.1f}, range {a['iters'].min()}..{a['iters'].max()}), "
               f"max difference {np.abs(a['iters'] - w4['iters']).max()}; where equal: positions max {e.max():.3f} mm, above 0.05 mm: {(e > 0.05).sum()}")
         assert same.mean() >= 0.97 and a["iters"].min() < a["iters"].max()
         assert (e > 0.05).sum() <= max(2, B // 1000) and np.percentile(e, 99.8) <= 0.05
-        again = _run(opts["none"], d, kernel="auto", **kw)
+        again = _run(o, d, kernel="auto", **kw)
         for k in a:
             np.testing.assert_array_equal(a[k], again[k])  # bitwise reproducible
