@@ -50,6 +50,7 @@ grep "dp_w16_kernel\|dp_w4_kernel\|\"Name\"" $(find $O/s4stats -name "*kernel_st
 python3 tools/w16_sweep.py 4096 5120 6144 8192 16384 32768 65536 131072 > $O/w16_sweep.txt 2>&1
 bash tools/w16_pmc.sh 16384 $O/w16_pmc_16384 > $O/w16_pmc_16384.txt 2>&1
 bash tools/w16_pmc.sh 65536 $O/w16_pmc_65536 > $O/w16_pmc_65536.txt 2>&1
+python3 tools/w16_early_stop_timing.py 2>/dev/null > $O/w16_early_stop.txt
 echo "w16 done"
 # 9. sequences: the whole operator in lock-step, the cost of a step of a whole-sequence launch, the plug-in
 python3 tools/throughput_sequences.py 6 2>&1 | grep "trackers" > $O/sequence_throughput.txt
