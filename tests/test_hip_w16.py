@@ -233,3 +233,34 @@ def test_early_stop_at_size_and_kernel_choice(opts, dev):
         again = _run(o, d, kernel="auto", **kw)
         for k in a:
             np.testing.assert_array_equal(a[k], again[k])  # bitwise reproducible
+
+
+def test_launches_are_graph_capturable(opts, dev):
+    """the large-batch kernel allocates nothing and never synchronises either: a captured launch (fixed count, then early stop)
+    replays bit for bit"""
+    from dragposer_amd.optimizer import to_device_batch
+
+    o = opts["none"]
+    d = to_device_batch(R.synth_inputs(R.OracleModel(), 8192, seed=4), dev)
+    for kw in (dict(n_iter=20), dict(n_iter=40, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5)):
+        out = o.allocate_outputs(8192)
+        want = {k: v.clone() for k, v in o.optimize(**d, out=out, **kw).items()}
+        assert o.kernel_geometry()[0] == 64
+        for v in out.values():
+            v.zero_()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            o.optimize(**d, out=out, **kw)  # (warm-up on the capture stream)
+        torch.cuda.current_stream().wait_stream(side)
+        for v in out.values():
+            v.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            o.optimize(**d, out=out, **kw)
+        for v in out.values():
+            v.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(out[k], want[k]), k
