@@ -1,5 +1,5 @@
-// dp_device.h -- device-side helpers shared by the optimise kernels (dp_w4.hip: wave-private, the product's kernel;
-// dp_kernel.hip: the previous decomposition, 8 waves per 16-frame workgroup, kept for comparisons).
+// dp_device.h -- device-side helpers shared by the optimise kernels (dp_w4.hip: 4 frames per wave; dp_w16*.hip: 16 frames per wave;
+// dp_kernel.hip: round 1's decomposition, 8 waves per 16-frame workgroup, kept in the test-only library for comparisons).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dp_kernel.h"

@@ -36,7 +36,8 @@ struct dp_ctx {
     int last_kernel = 0;   // what the last launch used: 4 = dp_w4.hip (8 in the test-only library, below)
 };
 
-// The product library has ONE optimise kernel (dp_w4.hip).  Round 1's 8-wave kernel (dp_kernel.hip: the reference's matrix
+// The product library has two optimise kernels: dp_w4.hip (4 frames per wave, fp32 MFMA) and dp_w16*.hip (16 frames per wave, bf16
+// MFMA in split precision, for batches beyond one round of the former): include/dragposer.h, DP_KERNEL_*.  Round 1's 8-wave kernel (dp_kernel.hip: the reference's matrix
 // chain taken literally, 16x16x4 tiles) survives as an independent second implementation for cross-checks in a TEST-ONLY
 // library, libdragposer_hip_ref8.so = this file compiled with -DDP_REF8_BUILD + dp_kernel.o; no environment variable is read.
 #ifdef DP_REF8_BUILD

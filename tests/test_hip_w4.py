@@ -1,4 +1,4 @@
-"""GPU (MI355X): the wave-private kernel (dp_w4.hip, what every launch uses) against the previous decomposition
+"""GPU (MI355X): the wave-private kernel (dp_w4.hip: every launch of up to 4096 frames, every sequence launch) against the previous decomposition
 (dp_kernel.hip, 16 frames per 8-wave workgroup: the test-only library libdragposer_hip_ref8.so).
 
 The two kernels are independent implementations of the same operator -- other tiling (v_mfma_f32_4x4x1 vs 16x16x4),
