@@ -9,7 +9,7 @@ at the last common point z(t* - 1):
     latents (the discontinuity of the gradient: slope 1 on one side, 0.2 on the other) -- the mechanism, shown directly;
   * the smallest |dL/dz| component (Adam's first steps move by lr * sign(g): a component within rounding of zero flips);
   * |z_gpu - z_oracle| just before and at t*.
-Usage: tools/soak_divergence.py [n_seeds] [kernel]"""
+Usage: tools/soak_divergence.py [n_seeds] [kernel] [first_seed]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +36,8 @@ def pre_acts(z):
 
 
 tot = dict(frames=0, kink_sign=0, kink_near=0, other=0)
-for seed in range(2000, 2000 + n_seeds):
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+for seed in range(seed0, seed0 + n_seeds):
     b = R.synth_inputs(m, 4096, seed=seed)
     o = opt.optimize(**to_device_batch(b, dev), n_iter=50, kernel=kernel)
     ref = A32.optimize(*[b[k] for k in KEYS], 50, lam_tmp=0.02)
