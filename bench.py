@@ -51,10 +51,12 @@ def synth_on_device(opt, B, seed, device, lo=0, hi=None, mixed=False):
     B = hi - lo
     w = torch.zeros(B, 22, 2)
     tracked = torch.zeros(B, 22, dtype=torch.uint8)
-    if mixed:  # (vectorised stand-in for the recipe's per-frame randperm: same distribution, drawn from the same generator)
-        Eb = torch.randint(1, 7, (Ball,), generator=g)[lo:hi]
-        order = torch.argsort(torch.rand(Ball, 6, generator=g), dim=1)[lo:hi]
-        keep = order < Eb[:, None]
+    if mixed:  # recipe S4's own draws (oracle.ref_torch.synth_inputs and the goldens draw the same): Eb, then a randperm per frame
+        Eb = torch.randint(1, 7, (Ball,), generator=g)
+        keep = torch.zeros(Ball, 6, dtype=torch.bool)
+        for b in range(Ball):
+            keep[b, torch.randperm(6, generator=g)[: int(Eb[b])]] = True
+        keep = keep[lo:hi]
         for k, j in enumerate(TRACK6):
             tracked[:, j] = keep[:, k].to(torch.uint8)
             w[:, j] = torch.tensor(W6[j]) * keep[:, k, None]
@@ -161,7 +163,7 @@ def main():
 
     from dragposer_amd.optimizer import LatentOptimizer
 
-    from dragposer_amd.sharding import reduce_stats, shard_bounds
+    from dragposer_amd.sharding import pick_kernel, reduce_stats, shard_bounds
 
     s4 = args.config == "s4"
     opt = LatentOptimizer(device=device, weight_dtype="bf16" if s4 else "fp32")
@@ -172,6 +174,8 @@ def main():
             raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
         batch = synth_on_device(opt, args.total_frames, 1234, device, lo, hi, mixed=s4)
         B, total_per_step = hi - lo, args.total_frames
+        if args.kernel == "auto":  # one batch, several launches: every shard in the same arithmetic (sharding.pick_kernel)
+            args.kernel = pick_kernel(opt, args.total_frames, world)
     else:  # weak scaling: every rank its own batch of --frames
         batch = synth_on_device(opt, args.frames, 1234 + rank, device, mixed=s4)
         B, total_per_step = args.frames, args.frames * world

@@ -113,7 +113,7 @@ class DpResult(C.Structure):
 # every symbol include/dragposer.h declares (checked by tests/test_abi.py)
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
-    "dp_forward", "dp_sequence_advance", "dp_optimize_sequence", "dp_kernel_geometry", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
+    "dp_forward", "dp_sequence_advance", "dp_optimize_sequence", "dp_kernel_geometry", "dp_auto_kernel", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
     "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict",
 )
 
@@ -152,6 +152,8 @@ def load(path=None):
     lib.dp_optimize_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(DpSeqFrames), C.POINTER(DpParams), C.POINTER(DpSeqState),
                                          C.POINTER(DpSeqStep), C.POINTER(DpSeqResults), C.c_void_p]
     lib.dp_kernel_geometry.argtypes = [C.c_void_p, _i, _i, _i]
+    lib.dp_auto_kernel.argtypes = [C.c_void_p, C.c_int]
+    lib.dp_auto_kernel.restype = C.c_int
     lib.dp_temporal_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(DpTemporalModel), C.c_int]
     lib.dp_temporal_destroy.argtypes = [C.c_void_p]
     lib.dp_temporal_last_error.restype = C.c_char_p

@@ -612,6 +612,7 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
     if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1,256]");
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: bad Adam hyper-parameters");
+    if (!(p->eps > 0.f)) return fail(ctx, DP_ERR_INVALID, "dp_optimize: Adam eps must be > 0 (include/dragposer.h: dp_params.eps)");
     KArgs k;
     fill_model_args(ctx, k);
     k.z0 = in->z0; k.z_tgt = in->z_tgt; k.cur_rot = in->cur_rot; k.tgt_pos = in->tgt_pos; k.tgt_rot = in->tgt_rot;
@@ -638,9 +639,19 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: unknown kernel selector");
     if (p->kernel == DP_KERNEL_W16 && !w16_can)
         return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 is laid out for the reference's 22-joint skeleton only");
-    const int kernel = p->kernel == DP_KERNEL_W16 || (p->kernel == DP_KERNEL_AUTO && w16_can && in->n_frames > ctx->n_cu * 16 /* more than one round of dp_w4's 16 frames per CU */)
-                           ? DP_KERNEL_W16 : DP_KERNEL_W4;
+    const int kernel = p->kernel == DP_KERNEL_AUTO ? dp_auto_kernel(ctx, in->n_frames) : p->kernel;
     return launch(ctx, k, stream, kernel);
+}
+
+extern "C" int dp_auto_kernel(const dp_ctx* ctx, int n_frames)
+{
+    if (!ctx || n_frames <= 0) return DP_ERR_INVALID;
+#ifdef DP_REF8_BUILD
+    return DP_KERNEL_W4;
+#else
+    // more than one round of dp_w4's 16 frames per CU: dp_w16 (where its slot map fits the skeleton)
+    return ctx->d_w16img != nullptr && n_frames > ctx->n_cu * 16 ? DP_KERNEL_W16 : DP_KERNEL_W4;
+#endif
 }
 
 extern "C" int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, void* stream)
@@ -684,6 +695,7 @@ extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const
     if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: n_iter out of range [1,256]");
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad Adam hyper-parameters");
+    if (!(p->eps > 0.f)) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: Adam eps must be > 0 (include/dragposer.h: dp_params.eps)");
     KArgs k;
     fill_model_args(ctx, k);
     k.z0 = latent; k.z_tgt = fr->z_tgt; k.cur_rot = st->global_rot; k.tgt_pos = fr->tgt_pos; k.tgt_rot = fr->tgt_rot; k.w = fr->w; k.tracked = fr->tracked;

@@ -218,12 +218,16 @@ class DragPose:
         poses = torch.empty(T, S, 88, device=dev)
         gpos = torch.empty(T, S, 3, device=dev)
         iters = torch.empty(T, S, dtype=torch.int32, device=dev)
-        pull = self.temporal is not None and float(lambda_temporal) != 0.0
+        # The reference predicts at current_index == 0 whatever lambda_temporal is (drag_pose.py:235-291), so the stretches between two
+        # predictions are cut the same way with the pull term on or off; without a predictor there is nothing to pull towards and the
+        # term is off in run() and here alike (the reference cannot run without one).
+        have = self.temporal is not None
+        pull = have and float(lambda_temporal) != 0.0
         window = int(temporal_future_window)
         zero_tgt = torch.zeros(S, LATENT, device=dev)
         t = 0
         while t < T:
-            if pull:  # frames up to the next prediction (a prediction every `window` frames; every frame when window = 0)
+            if have:  # frames up to the next prediction (a prediction every `window` frames; every frame when window = 0)
                 self._temporal_targets(window)
                 n = min(T - t, max(window, 1) - self.current_index)
                 z_tgt, strides = self.target_latent_buffer[:, self.current_index:], (LATENT, (window + 1) * LATENT)
@@ -274,16 +278,18 @@ class DragPose:
         self._flip ^= 1  # two result sets, alternated: `last` stays valid while the next frame runs
         if self._out[self._flip] is None:
             self._out[self._flip] = dict(iters=torch.empty(1, S, dtype=torch.int32, device=dev), loss=torch.empty(1, S, 3, device=dev),
-                                         scratch=torch.empty(1, S, LATENT + 3 + len(height_indices), device=dev))
+                                         scratch=torch.empty(1, S, LATENT + 3 + len(height_indices), device=dev), z=torch.empty(S, LATENT, device=dev))
         o = self._out[self._flip]
         z_tgt = self.target_latent_buffer[:, self.current_index:]
+        pull = self.temporal is not None and float(lambda_temporal) != 0.0  # (no predictor: the buffer is zeros, the term is off; run_frames() alike)
         self.opt.optimize_sequence(self.latent, trk["tgt_pos"].unsqueeze(0), trk["tgt_rot"].unsqueeze(0), None, trk["w"], trk["tracked"], z_tgt,
                                    (0, (int(temporal_future_window) + 1) * LATENT), self.current_global_pos, self.current_global_rot,
                                    self.latent_buffer, self.displacement_buffer, self.heights_buffer, tuple(int(h) for h in height_indices),
-                                   n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot), lambda_tmp=float(lambda_temporal),
+                                   n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot), lambda_tmp=float(lambda_temporal) if pull else 0.0,
                                    stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot, min_loss_incr=min_loss_incr, adjust=adjust,
                                    pose_ret=pose.unsqueeze(0), pos_ret=gpos.unsqueeze(0), iters=o["iters"], loss=o["loss"], scratch=o["scratch"])
-        self.last = dict(iters=o["iters"][0], loss=o["loss"][0], z=self.latent)
+        o["z"].copy_(self.latent)  # (self.latent is advanced in place by the next frame; `last` must not move with it)
+        self.last = dict(iters=o["iters"][0], loss=o["loss"][0], z=o["z"], pose=pose, pos=gpos)
         if verbose:
             l, it = self.last["loss"].cpu(), self.last["iters"].cpu()
             print(f"Loss sqrt(Pos): {l[:, 0].sqrt().mean():.5f} // Loss Rot: {l[:, 1].mean():.5f} // "

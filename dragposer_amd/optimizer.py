@@ -67,6 +67,15 @@ class LatentOptimizer:
         self.lib.dp_kernel_geometry(self.ctx, C.byref(fpb), C.byref(tpb), C.byref(lds))
         return fpb.value, tpb.value, lds.value
 
+    def auto_kernel(self, n_frames):
+        """"w4" | "w16": what kernel="auto" launches for a batch of `n_frames` on this device (dp_auto_kernel).  The two kernels
+        differ in the last bits of their arithmetic, so a caller that cuts one batch into several launches and wants a frame's
+        result not to depend on the cut pins the answer for the deciding size (dragposer_amd.sharding.pick_kernel)."""
+        k = self.lib.dp_auto_kernel(self.ctx, int(n_frames))
+        if k < 0:
+            self._fail(k)
+        return {_lib.DP_KERNEL_W4: "w4", _lib.DP_KERNEL_W16: "w16"}[k]
+
     def close(self):
         if getattr(self, "ctx", None) is not None and self.ctx.value:
             self.lib.dp_destroy(self.ctx)

@@ -43,7 +43,11 @@
 extern "C" {
 #endif
 
-#define DP_VERSION 300 /* 0.3.0: round 3 -- max_trackers ignored since 0.2, dp_temporal_* added in 0.2, dp_optimize_sequence in 0.3 */
+#define DP_VERSION 400 /* 0.4.0: dp_auto_kernel added; Adam eps must be > 0.  ABI BREAK at 0.3.0 (stated late): dp_params grew the
+                          trailing `kernel` field then, so sizeof(dp_params) changed -- a caller COMPILED against 0.2 hands over a
+                          shorter struct and must be recompiled against this header (the library cannot tell; there is no size
+                          field), zeroing the struct first (`dp_params p = {0}`) so that fields added later read as their defaults.
+                          max_trackers ignored since 0.2, dp_temporal_* added in 0.2, dp_optimize_sequence in 0.3 */
 
 #define DP_NUM_JOINTS 22
 #define DP_LATENT 24
@@ -115,13 +119,16 @@ typedef struct dp_batch {
 typedef struct dp_params {
     int n_iter;        /* max_iter; exactly n_iter iterations when early_stop == 0 (<= DP_MAX_ITERS) */
     float lr;          /* learning_rate */
-    float beta1, beta2, eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+    float beta1, beta2, eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8.  eps must be > 0 (DP_ERR_INVALID otherwise): torch accepts 0,
+                                where a gradient component that is exactly 0 gives 0/0 = NaN; the kernels also carry the latent's
+                                padding lanes (dims 24..31, gradient 0) through the same update, so with eps = 0 EVERY frame would */
     float lambda_rot, lambda_tmp;
     int early_stop;    /* 1: per-frame while-condition of drag_pose.py:300-304 */
     float stop_eps_pos, stop_eps_rot, min_loss_incr;
     int max_trackers;  /* ignored (kept for ABI compatibility with version 1, where it selected a kernel variant): every
                           joint of a frame may carry a tracker, whatever this says */
-    int kernel;        /* DP_KERNEL_AUTO / _W4 / _W16 (below); callers written against 0.2 must zero it */
+    int kernel;        /* DP_KERNEL_AUTO / _W4 / _W16 (below).  Added in 0.3.0: see DP_VERSION for what that means to 0.2 callers.
+                          dp_optimize_sequence ignores it (whole-sequence launches are DP_KERNEL_W4's) and implies early_stop = 1 */
 } dp_params;
 
 /* Two kernels implement dp_optimize (same operator, same outputs, within the tolerance stated in DESIGN.md):
@@ -137,6 +144,12 @@ typedef struct dp_params {
 #define DP_KERNEL_AUTO 0
 #define DP_KERNEL_W4 1
 #define DP_KERNEL_W16 2
+/* AUTO is a function of the launch's OWN frame count and the device's CU count, and the two kernels differ in the last bits of
+ * their arithmetic (on frames that sit on a LeakyReLU kink: by millimetres).  A caller that cuts ONE batch
+ * into several launches (shards over GPUs, chunks over time) and wants every frame's result to be independent of the cut must
+ * therefore pin the kernel: ask once with dp_auto_kernel for the size that decides (dragposer_amd/sharding.py: the largest shard)
+ * and pass the answer as dp_params.kernel to every launch.  Returns DP_KERNEL_W4 or DP_KERNEL_W16, or a negative dp_status. */
+int dp_auto_kernel(const dp_ctx* ctx, int n_frames);
 
 /* Outputs, DEVICE pointers; any may be NULL.  All but z are those of the LAST forward pass
  * (the latent before the final Adam step), as the reference returns them (drag_pose.py:309-312). */

@@ -82,6 +82,12 @@ def test_golden_parity(opts, dev, golden_dir, name):
 
 
 def test_three_trackers_against_the_reference(opts, dev, golden_dir):
+    """BASELINE config 4 on the 64-frame fixture, in BASELINE's terms (mean <= 0.05, p99 <= 1, max <= 3 mm over B x 22).  One of the
+    64 frames (14) is one the REFERENCE cannot reproduce between its own fp32 and fp64 runs (2.14 mm apart): its 22 joints are 1.6 %
+    of the sample, i.e. they ARE the p99 -- with that frame this kernel measures p99 1.01 / max 5.03 mm, dp_w4 0.38 / 1.92, the
+    reference's own pair 0.25 / 2.14: three draws of a chaotic frame.  So the bars are asserted off the reference-flagged frames
+    (where an implementation-independent answer exists), the flagged ones are bounded, and the question whether dp_w16 is worse
+    than dp_w4 on config 4 is settled at size (1024 frames, tests/test_hip_configs_at_size.py), not on one frame."""
     from dragposer_amd.optimizer import to_device_batch
 
     g = R.load_golden(os.path.join(golden_dir, "s3.npz"))
@@ -89,8 +95,12 @@ def test_three_trackers_against_the_reference(opts, dev, golden_dir):
     o = _run(opts["none"], to_device_batch(g, dev), n_iter=mt["n_iter"], lambda_tmp=mt["lambda_tmp"], kernel="w16")
     e = _mm(o["pos"], g["pos"])
     sens = _mm(g["pos"], g["pos_f64"]).max(axis=1) > 0.02  # frames the reference's own fp32 / fp64 runs disagree on
-    print(f"s3 (w16): mean {e.mean():.4f} mm, p99 {np.percentile(e, 99):.4f}, max {e.max():.4f}; off the reference-flagged frames {e[~sens].max():.4f}")
-    assert e.mean() <= 0.05 and e[~sens].max() <= 0.05 and e[sens].max() <= 10.0
+    print(f"s3 (w16): all frames mean {e.mean():.4f} mm, p99 {np.percentile(e, 99):.4f}, max {e.max():.4f}; off the reference-flagged frames "
+          f"{np.nonzero(sens)[0].tolist()}: mean {e[~sens].mean():.5f}, p99 {np.percentile(e[~sens], 99):.5f}, max {e[~sens].max():.4f}")
+    assert e.mean() <= 0.05
+    assert e[~sens].mean() <= 0.05 and np.percentile(e[~sens], 99) <= 1.0 and e[~sens].max() <= 3.0  # BASELINE's three bars
+    assert e[~sens].max() <= 0.05  # (what the kernel actually achieves there)
+    assert sens.sum() <= 2 and e[sens].max() <= 10.0
 
 
 @pytest.mark.parametrize("B", [1, 15, 17, 100])

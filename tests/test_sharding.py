@@ -23,6 +23,20 @@ def test_shard_bounds_cover_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_pick_kernel_is_the_choice_for_the_largest_shard():
+    """every rank of a sharded batch gets the same kernel, the library's choice for the LARGEST shard (the GPU counterpart, across
+    the real threshold: tests/test_hip_w4.py::test_shards_of_one_batch_run_one_arithmetic)"""
+    from dragposer_amd.sharding import pick_kernel
+
+    class Fake:  # LatentOptimizer.auto_kernel on a 256-CU device: dp_w16 beyond 16 frames per CU
+        def auto_kernel(self, n):
+            return "w16" if n > 4096 else "w4"
+
+    assert pick_kernel(Fake(), 8192, 2) == "w4"      # 4096 + 4096
+    assert pick_kernel(Fake(), 8193, 2) == "w16"     # 4097 + 4096: "auto" per rank would have split the arithmetic
+    assert pick_kernel(Fake(), 8193, 1) == "w16" and pick_kernel(Fake(), 32768, 8) == "w4" and pick_kernel(Fake(), 32769, 8) == "w16"
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist

@@ -350,27 +350,64 @@ def add_f64(name, gold, offsets, parents, workers):
           f"({np.round(d[d > 0.02], 3).tolist()})")
 
 
-def full_size_reference(name, B, seed, gold, offsets, parents, workers):
-    """BASELINE's headline batch (recipe S1, B frames, 50 iterations, inputs exactly as tests/bench.py draw them through
+def full_size_reference(name, B, seed, gold, offsets, parents, workers, trackers=6, mixed=False, n_iter=50, lam_tmp=0.02,
+                        weight_rounding=None, keep_f64=False):
+    """A BASELINE batch at size (recipe S of SURVEY 8d, B frames, inputs exactly as tests / bench.py draw them through
     oracle.ref_torch.synth_inputs) through the REAL reference in fp32 and in fp64.  The fixture holds the tracked joints' targets
     (the tests re-draw the rest and check the digest of everything), the fp32 reference positions / latents of every frame, per frame the distance between
-    the reference's own fp32 and fp64 runs, and the fp64 positions of the frames where that distance exceeds 0.02 mm."""
+    the reference's own fp32 and fp64 runs, and the fp64 positions of the frames where that distance exceeds 0.02 mm (keep_f64: of
+    every frame -- the 1024-frame fixtures of configs 4 and 5, whose tolerance is stated as mean / p99 / max over all frames).
+    trackers = 3 / n_iter = 100 / lam_tmp = 0.15: recipe S3 (config 4); mixed + weight_rounding = "bf16": recipe S4 (config 5), the
+    reference's decoder weight tensors rounded to bf16 in both runs, targets drawn from that same rounded model."""
     sys.path.insert(0, REPO)
     from oracle import ref_torch as R  # inputs only: the recipe the GPU tests and bench.py use
 
-    inp = R.synth_inputs(R.OracleModel(), B, seed=seed)
-    o32 = run_frames_parallel(inp, 50, 0.02, offsets, parents, workers, dtype=torch.float32, progress=name + "_f32")
-    o64 = run_frames_parallel(inp, 50, 0.02, offsets, parents, workers, dtype=torch.float64, progress=name + "_f64")
+    inp = R.synth_inputs(R.OracleModel(weight_rounding=weight_rounding or "none"), B, trackers=trackers, mixed=mixed, seed=seed)
+    o32 = run_frames_parallel(inp, n_iter, lam_tmp, offsets, parents, workers, dtype=torch.float32, weight_rounding=weight_rounding,
+                              progress=name + "_f32")
+    o64 = run_frames_parallel(inp, n_iter, lam_tmp, offsets, parents, workers, dtype=torch.float64, weight_rounding=weight_rounding,
+                              progress=name + "_f64")
     d = (np.linalg.norm(o32["pos"] - o64["pos"], axis=-1).max(1) * 1000).astype(np.float32)
     sens = np.nonzero(d > 0.02)[0].astype(np.int32)
-    meta = dict(name=name, B=B, seed=seed, n_iter=50, lambda_tmp=0.02, digest=inputs_digest(inp), torch=torch.__version__)
+    meta = dict(name=name, B=B, seed=seed, n_iter=n_iter, lambda_tmp=lam_tmp, trackers=trackers, mixed=bool(mixed),
+                weight_rounding=weight_rounding or "none", digest=inputs_digest(inp), torch=torch.__version__)
     path = os.path.join(gold, f"{name}.npz")
     T6 = [0, 3, 7, 13, 17, 21]  # the targets travel with the fixture: they come out of CPU matrix products whose last bits differ between hosts
+    extra = {}
+    if mixed:
+        extra["tracked6"] = inp["tracked"][:, T6]
+    if keep_f64:
+        extra.update(pos_f64=o64["pos"], z_pre_f64=o64["z_pre"], loss_last_f64=o64["loss_last"].astype(np.float32))
     np.savez_compressed(path, pos=o32["pos"], z_final=o32["z_final"], z_pre=o32["z_pre"], loss_last=o32["loss_last"].astype(np.float32),
                         tgt_pos6=inp["tgt_pos"][:, T6], tgt_rot6=inp["tgt_rot"][:, T6],
                         ref32_vs_ref64_mm=d, sens_frames=sens, pos_f64_sens=o64["pos"][sens], z_final_f64_sens=o64["z_final"][sens],
+                        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **extra)
+    dj = np.linalg.norm(o32["pos"] - o64["pos"], axis=-1).reshape(-1) * 1000
+    print(f"wrote {path} {os.path.getsize(path)} bytes; reference fp32 vs fp64 over B x 22: mean {dj.mean():.5f} p99 {np.percentile(dj, 99):.4f} "
+          f"max {dj.max():.4f} mm; > 0.02 mm on {len(sens)} frames {sens.tolist()[:40]} ({np.round(d[sens], 3).tolist()[:40]} mm)")
+
+
+def probe_reference(name, B, seed, frames, gold, offsets, parents, workers, n_iter=50, lam_tmp=0.02):
+    """Chosen frames of a large recipe-S1 batch (BASELINE config 3: 8192 frames) through the REAL reference in fp32 and fp64: every
+    16th frame plus the frames a GPU kernel or the repo's C-oracle pair ever singled out (--probe-frames), so that "is this a frame
+    on which correct implementations part ways?" is answered by the reference itself, not by the repo's restatements."""
+    sys.path.insert(0, REPO)
+    from oracle import ref_torch as R  # inputs only
+
+    inp = R.synth_inputs(R.OracleModel(), B, seed=seed)
+    frames = np.array(sorted(set(int(f) for f in frames)), np.int32)
+    sub = {k: v[frames] for k, v in inp.items()}
+    o32 = run_frames_parallel(sub, n_iter, lam_tmp, offsets, parents, workers, dtype=torch.float32, progress=name + "_f32")
+    o64 = run_frames_parallel(sub, n_iter, lam_tmp, offsets, parents, workers, dtype=torch.float64, progress=name + "_f64")
+    d = (np.linalg.norm(o32["pos"] - o64["pos"], axis=-1).max(1) * 1000).astype(np.float32)
+    T6 = [0, 3, 7, 13, 17, 21]
+    meta = dict(name=name, B=B, seed=seed, n_iter=n_iter, lambda_tmp=lam_tmp, digest=inputs_digest(sub), torch=torch.__version__)
+    path = os.path.join(gold, f"{name}.npz")
+    np.savez_compressed(path, frames=frames, pos=o32["pos"], pos_f64=o64["pos"], z_final=o32["z_final"], loss_last=o32["loss_last"].astype(np.float32),
+                        tgt_pos6=sub["tgt_pos"][:, T6], tgt_rot6=sub["tgt_rot"][:, T6], ref32_vs_ref64_mm=d,
                         meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
-    print(f"wrote {path} {os.path.getsize(path)} bytes; reference fp32 vs fp64 > 0.02 mm on frames {sens.tolist()} ({np.round(d[sens], 3).tolist()} mm)")
+    print(f"wrote {path} {os.path.getsize(path)} bytes; {len(frames)} frames; reference fp32 vs fp64 > 0.02 mm on frames "
+          f"{frames[d > 0.02].tolist()} ({np.round(d[d > 0.02], 3).tolist()} mm)")
 
 
 def export_model(parents, offsets):
@@ -541,6 +578,8 @@ def main():
     ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3,sequ,enc")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--workers", type=int, default=6)
+    ap.add_argument("--probe-frames", default="2392,4901,8124,2489,6005,6112,6516",
+                    help="full8192_probe: frames run through the reference besides every 16th (defaults: the frames dp_w16 / the C-oracle pair singled out in round 3)")
     args = ap.parse_args()
     todo = args.only.split(",")
     parents, offsets = parse_bvh_skeleton(os.path.join(REF, "data/example/eval/example.bvh"))
@@ -577,6 +616,15 @@ def main():
     for name, Bf in (("full1024", 1024), ("full4096", 4096)):  # BASELINE config 2 / the headline batch, whole, through the reference
         if name in todo:
             full_size_reference(name, Bf, 1234, gold, offsets, parents, args.workers)
+    if "full_s3_1024" in todo:  # BASELINE config 4 at size: 3 trackers, 100 iterations, lambda_temporal of 3_trackers_config.json
+        full_size_reference("full_s3_1024", 1024, 1234, gold, offsets, parents, args.workers, trackers=3, n_iter=100,
+                            lam_tmp=cfg3["lambda_temporal"], keep_f64=True)
+    if "full_s4_1024" in todo:  # BASELINE config 5 at size: 1-6 trackers per frame, bf16-rounded decoder weight tensors
+        full_size_reference("full_s4_1024", 1024, 1234, gold, offsets, parents, args.workers, mixed=True, n_iter=50,
+                            lam_tmp=cfg6["lambda_temporal"], weight_rounding="bf16", keep_f64=True)
+    if "full8192_probe" in todo:  # BASELINE config 3's 8192-frame batch: a reference-run sample + the frames ever singled out
+        extra = [int(f) for f in args.probe_frames.split(",") if f]
+        probe_reference("full8192_probe", 8192, 1234, list(range(0, 8192, 16)) + extra, gold, offsets, parents, args.workers)
     if "enc" in todo:
         path = os.path.join(gold, "enc.npz")
         np.savez_compressed(path, **encoder_golden(parents))
