@@ -64,6 +64,18 @@ def result_to_bvh(poses, global_pos, means, stds, bvh, out_path):
     bvh.save(out_path)
 
 
+def synthesize_targets(m, n_frames, mask_idx):
+    """The per-frame targets of eval_drag.py:164-202 that do not depend on the running state: ground-truth root-space quaternions
+    with the root channel replaced by the global rotation -> parent-local (from_root_quat) -> FK with the root at the origin.
+    -> positions of the tracked joints relative to the root [F, E, 3] (the reference adds target_global_pos - current_global_pos
+    to them, frame by frame: run_sequences does that on the device) and their global rotation matrices [F, E, 9]."""
+    rq = m["root_quats"].copy()
+    rq[:, 0] = m["global_rot"]
+    local = Q.from_root_space(rq, m["parents"])
+    p_rel, g_rot = Q.fk(local[:n_frames], np.zeros((n_frames, 3)), m["offsets"].astype(np.float64), m["parents"])
+    return p_rel[:, mask_idx], Q.to_matrix(g_rot[:, mask_idx]).reshape(n_frames, len(mask_idx), 9)
+
+
 def prepare_file(args, input_path, opt, encoder, cfg, raw):
     """BVH -> everything one sequence needs on the device (eval_drag.py:133-202): normalised motion, per-frame
     targets relative to the root, the ground-truth root trajectory, the encoder's initial latent."""
@@ -78,15 +90,16 @@ def prepare_file(args, input_path, opt, encoder, cfg, raw):
     mask_idx = np.nonzero(np.asarray(cfg["mask"]))[0]
     # targets (eval_drag.py:164-202): FK of the ground-truth pose with the root at the origin, per frame; the
     # root translation relative to the running estimate is added inside the loop, on the device
-    rq = m["root_quats"].copy()
-    rq[:, 0] = m["global_rot"]
-    local = Q.from_root_space(rq, m["parents"])
-    p_rel, g_rot = Q.fk(local[:n_frames], np.zeros((n_frames, 3)), m["offsets"].astype(np.float64), m["parents"])
-    gen = torch.Generator(device="cpu").manual_seed(2222)  # train.param["seed"]
-    z0 = encoder.sample(torch.tensor(m["dqs"][0:1], device=dev), generator=gen)  # drag_pose.py:50
+    p_rel, r_mats = synthesize_targets(m, n_frames, mask_idx)
+    if getattr(args, "initial_latent", None):
+        # (parity runs: the reference draws the encoder's noise from torch's GLOBAL generator after its model constructors have
+        #  consumed an implementation-defined amount of it -- eval_drag.py:23,49-51,152 -- so its latent is handed over instead)
+        z0 = torch.tensor(np.load(args.initial_latent).reshape(1, -1), dtype=torch.float32, device=dev)
+    else:
+        gen = torch.Generator(device="cpu").manual_seed(2222)  # train.param["seed"]
+        z0 = encoder.sample(torch.tensor(m["dqs"][0:1], device=dev), generator=gen)  # drag_pose.py:50
     return dict(path=input_path, bvh=bvh, m=m, n_frames=n_frames, means=means, stds=stds, z0=z0,
-                tp_rel=torch.tensor(p_rel[:, mask_idx], dtype=torch.float32, device=dev),
-                tR=torch.tensor(Q.to_matrix(g_rot[:, mask_idx]).reshape(n_frames, len(mask_idx), 9), dtype=torch.float32, device=dev),
+                tp_rel=torch.tensor(p_rel, dtype=torch.float32, device=dev), tR=torch.tensor(r_mats, dtype=torch.float32, device=dev),
                 gpos=torch.tensor(m["global_pos"][:n_frames], dtype=torch.float32, device=dev))
 
 
@@ -150,7 +163,10 @@ def finish_file(args, q, res, elapsed, lam_tmp, has_temporal, shared=1):
     print(f"Time: {elapsed}" + (f"  (shared by {shared} sequences in lock-step)" if shared > 1 else ""))
     print(f"Frames: {n}  ({n / elapsed:.1f} frames/s, mean iterations/frame {res['iters'].mean():.1f}, "
           f"lambda_temporal {lam_tmp}{'' if has_temporal else ' -- no temporal checkpoint given: pull term off'})")
-    return dict(mpjpe=mpjpe, mpeepe=mpeepe, time=elapsed, frames=n, out=out_path, mean_iters=float(res["iters"].mean()))
+    out = dict(mpjpe=mpjpe, mpeepe=mpeepe, time=elapsed, frames=n, out=out_path, mean_iters=float(res["iters"].mean()))
+    if getattr(args, "keep_frames", False):
+        out.update(poses=res["poses"], pos=res["pos"], iters=res["iters"])
+    return out
 
 
 def evaluate_files(args, paths, opt, encoder, temporal_pack, cfg, raw):
@@ -183,6 +199,10 @@ def main(argv=None):
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--out-dir", default="data")
+    ap.add_argument("--keep-frames", action="store_true", help="callers of main(): also return the per-frame poses / global positions / iteration counts")
+    ap.add_argument("--initial-latent", default=None,
+                    help=".npy with the 24 numbers of the initial latent (instead of encoder(mu, logvar) + a seeded normal draw): for parity runs against "
+                         "a recorded reference run, whose own draw depends on how much of torch's global generator its constructors consumed")
     ap.add_argument("--per-frame", action="store_true",
                     help="drive the frame loop from the host, one DragPose.run (two launches) per frame, as the reference does (default: the "
                          "frame loop runs on the device, DragPose.run_frames; same results)")

@@ -57,6 +57,11 @@ class TemporalPredictor(nn.Module):
 def load_reference_checkpoint(path, device="cpu", **arch):
     """temporal.pt as saved by the reference (train.py:308-318): model_state_dict + latent statistics."""
     ck = torch.load(path, map_location=device)
+    sd = ck["model_state_dict"]
+    # layer counts and feed-forward width from the tensors themselves (train_temporal.param holds them in the reference: 3 / 3 / 2048)
+    n_layers = lambda part: 1 + max(int(k.split(".")[3]) for k in sd if k.startswith(f"temporal.{part}.layers."))
+    arch = dict(dict(n_encoder_layers=n_layers("encoder"), n_decoder_layers=n_layers("decoder"),
+                     dim_feedforward=int(sd["temporal.encoder.layers.0.linear1.weight"].shape[0])), **arch)
     model = TemporalPredictor(**arch).to(device)
     model.load_state_dict(ck["model_state_dict"])
     return model.eval(), ck["means_latent"].to(device), ck["stds_latent"].to(device)

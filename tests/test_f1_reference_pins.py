@@ -1,0 +1,134 @@
+"""CPU: the evaluation pipeline (BASELINE config 1) against what the REFERENCE'S OWN plumbing produced.
+
+tests/golden/f1_*.npz are recordings of the reference's `eval_drag.main` (eval_drag.py:21-252) executed from /root/reference by
+tools/make_f1_goldens.py: its `get_info_from_bvh` (train.py:329-341), `TestMotionData.add_motion / normalize`
+(motion_data.py:225-324), `set_initial_pose` (drag_pose.py:47-64), per-frame target synthesis (eval_drag.py:164-202),
+`result_to_bvh` (train.py:437-509) and `eval_pos_error` (eval_metrics.py:6-32).  Held to them here: dragposer_amd/motion.py,
+bvh.py, encoder.py and the host functions of dragposer_amd/eval_drag.py.  (The optimisation between targets and results runs on
+the GPU: tests/test_hip_f1.py.)
+
+What these fixtures cannot pin: the primitives of the absent `upc-pymotion` package (Euler composition order, the dual part of a
+dual quaternion, unroll's sign rule, the BVH parser) -- the reference ran on tools/pymotion_standin, i.e. on this repo's own numpy
+primitives behind pymotion's API, so they are common to both sides.  Everything the reference BUILDS on them is pinned.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dragposer_amd import motion as MO
+from dragposer_amd.bvh import BVH
+from dragposer_amd.encoder import PoseEncoder
+from dragposer_amd.eval_drag import eval_pos_error, result_to_bvh, synthesize_targets
+from oracle import ref_torch as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLIPS = ["f1_clip6", "f1_clip3", "f1_clip6_t", "f1_clip3_t"]
+
+
+def load(golden_dir, name):
+    raw = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    g = {k: raw[k] for k in raw.files if k != "meta"}
+    g["meta"] = json.loads(bytes(raw["meta"]).decode())
+    return g
+
+
+def bvh_path(g):
+    name = g["meta"]["bvh"]
+    p = os.path.join(ROOT, "tests", "data", name) if name == "example_clip.bvh" else os.path.join(ROOT, "tests", "data", "_local", name)
+    if not os.path.exists(p):
+        pytest.skip(f"{name} not staged (python -c 'import __graft_entry__ as g; g.build()' where the reference is mounted)")
+    return p
+
+
+@pytest.fixture(scope="module")
+def stats():
+    raw = np.load(R.DEFAULT_MODEL)
+    return ({"dqs": raw["means.dqs"], "displacement": raw["means.displacement"]},
+            {"dqs": raw["stds.dqs"], "displacement": raw["stds.displacement"]}, raw)
+
+
+@pytest.mark.parametrize("name", ["f1_clip6", "f1_example"])
+def test_preprocessing_equals_the_references_test_motion_data(golden_dir, stats, name):
+    """BVH -> normalised root-space dual quaternions, root trajectory, heights: TestMotionData.add_motion + normalize"""
+    g = load(golden_dir, name)
+    means, stds, _ = stats
+    m = MO.prepare_motion(BVH().load(bvh_path(g)), means, stds)
+    idx = g["sample"]
+    assert len(m["dqs"]) == int(g["n_frames"])
+    # in the units of the data (de-normalised): fp32 storage of the fixture is the only difference
+    sd, mu = stds["dqs"].astype(np.float64), means["dqs"].astype(np.float64)
+    np.testing.assert_allclose(m["dqs"][idx].astype(np.float64) * sd + mu, g["dqs"].astype(np.float64) * sd + mu, atol=3e-6)
+    np.testing.assert_allclose(m["dqs"][idx], g["dqs"], atol=2e-2)  # normalised: some channels have sigma 6e-4 (x 1700)
+    np.testing.assert_allclose(m["global_pos"], g["global_pos"], atol=1e-6)
+    np.testing.assert_allclose(m["global_rot"], g["global_rot"], atol=1e-6)
+    np.testing.assert_allclose(m["heights"], g["heights"], atol=2e-6)
+    disp_n = (m["displacement"] - means["displacement"]) / stds["displacement"]
+    np.testing.assert_allclose(disp_n[idx], g["displacement"], atol=2e-3)
+    # every frame, not only the stored sample: column sums of the normalised channels over the whole file
+    np.testing.assert_allclose(m["dqs"].astype(np.float64).sum(0), g["dqs_colsum"], atol=2e-2 * np.sqrt(len(m["dqs"])) + 1e-3 * len(m["dqs"]) ** 0.5)
+    np.testing.assert_allclose(np.abs(m["dqs"].astype(np.float64)).sum(0), g["dqs_colabs"], rtol=1e-4, atol=0.5)
+
+
+@pytest.mark.parametrize("name", ["f1_clip6", "f1_clip3", "f1_example"])
+def test_targets_equal_the_references_per_frame_synthesis(golden_dir, stats, name):
+    """eval_drag.py:164-202: what DragPose.run received as target_ee_pos / target_ee_rot, frame by frame.  The position targets are
+    relative to the RUNNING global position (recorded in the fixture): ours are root-relative + (target root - running position)."""
+    g = load(golden_dir, name)
+    means, stds, _ = stats
+    m = MO.prepare_motion(BVH().load(bvh_path(g)), means, stds)
+    mask_idx = np.nonzero(np.asarray(g["meta"]["cfg"]["mask"]))[0]
+    p_rel, r_mats = synthesize_targets(m, int(g["n_frames"]), mask_idx)
+    idx = g["sample"]
+    tp = p_rel[idx] + (m["global_pos"][idx].astype(np.float64) - g["gpos_before"][idx].astype(np.float64))[:, None, :]
+    np.testing.assert_allclose(tp, g["tgt_pos"], atol=3e-6)
+    np.testing.assert_allclose(r_mats[idx].reshape(len(idx), -1, 3, 3), g["tgt_rot"], atol=3e-6)
+
+
+def test_initial_latent_statistics_equal_the_references_encoder(golden_dir, stats):
+    """set_initial_pose (drag_pose.py:47-64): encoder(mu, logvar) of the first frame's pose; the reference's normal draw is
+    recovered from its latent and reproduces it through the same formula"""
+    g = load(golden_dir, "f1_clip6")
+    means, stds, _ = stats
+    m = MO.prepare_motion(BVH().load(bvh_path(g)), means, stds)
+    np.testing.assert_allclose(m["dqs"][0], g["initial_pose"], atol=2e-2)
+    with torch.no_grad():
+        mu, logvar = PoseEncoder()(torch.tensor(g["initial_pose"][None]))
+    np.testing.assert_allclose(mu.numpy()[0], g["initial_mu"], atol=2e-5)
+    np.testing.assert_allclose(logvar.numpy()[0], g["initial_logvar"], atol=2e-5)
+    eps = (g["initial_latent"] - g["initial_mu"]) / np.exp(0.5 * g["initial_logvar"])
+    np.testing.assert_allclose(mu.numpy()[0] + eps * np.exp(0.5 * logvar.numpy()[0]), g["initial_latent"], atol=2e-5)
+    np.testing.assert_allclose(m["heights"][0], g["initial_heights"], atol=2e-6)
+
+
+@pytest.mark.parametrize("name", CLIPS)
+def test_result_file_and_metrics_equal_the_references(golden_dir, stats, tmp_path, name):
+    """train.result_to_bvh (are_root_rot_incr=False) on the poses / global positions the REFERENCE's run returned -> the MOTION block
+    it wrote; then eval_metrics.eval_pos_error of that file against the ground truth -> its two printed numbers."""
+    g = load(golden_dir, name)
+    means, stds, _ = stats
+    src = bvh_path(g)
+    out = str(tmp_path / "eval.bvh")
+    result_to_bvh(g["pose_ret_all"], g["gpos_ret"], means, stds, BVH().load(src), out)
+    mine = BVH().load(out).motion
+    ref = g["result_motion_all"]
+    assert mine.shape == ref.shape
+    d = np.abs(mine - ref)
+    d[:, 3:] = np.minimum(d[:, 3:], np.abs(d[:, 3:] - 360.0))  # (an angle at +-180 degrees may print on either side)
+    assert d.max() <= 2e-4, d.max()  # (the reference's writer prints 6 decimals too)
+    mpjpe, mpeepe = eval_pos_error(BVH().load(src), BVH().load(out))
+    np.testing.assert_allclose([mpjpe, mpeepe], [float(g["mpjpe"]), float(g["mpeepe"])], rtol=2e-5)
+
+
+def test_reference_run_statistics_are_what_the_fixture_says(golden_dir):
+    """the long file's recording, internally: one iteration count and one returned global position per frame, iteration counts
+    within run()'s bounds, the stored sample strided as stated -- and the figures DESIGN.md quotes"""
+    g = load(golden_dir, "f1_example")
+    T = int(g["n_frames"])
+    assert T == 5052 and g["iters"].shape == (T,) and g["gpos_ret"].shape == (T, 3)
+    assert g["iters"].min() >= 1 and g["iters"].max() <= 100
+    assert set(np.arange(0, T, g["meta"]["stride"])) <= set(g["sample"].tolist())
+    print(f"reference on example.bvh (lambda_temporal 0): iterations/frame mean {g['iters'].mean():.2f}, MPJPE {float(g['mpjpe']) * 1000:.2f} mm, "
+          f"MPEEPE {float(g['mpeepe']) * 1000:.2f} mm")

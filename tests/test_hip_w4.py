@@ -261,7 +261,7 @@ def test_baseline_config_batches_against_the_c_oracle(opt, dev, golden_dir, B):
     assert sens.sum() <= max(2, B // 1000) and len(bad) <= max(2, B // 1000) and ok.all(), (bad, kink, tiny)
     assert all(e <= 5.0 or bt for e, bt in zip(err[bad], better)), (err[bad], better)
     good = err <= 0.05
-    np.testing.assert_allclose(o["loss"][good & ~sens], r32["loss"][good & ~sens], rtol=2e-3, atol=1e-8)
+    np.testing.assert_allclose(o["loss"][good & ~sens & ~osens], r32["loss"][good & ~sens & ~osens], rtol=2e-3, atol=1e-8)  # (the C oracle's fp32 losses: not where its own pair parts ways)
     assert (o["iters"] == 50).all()
 
 

@@ -1,6 +1,33 @@
-"""placeholder (off the hot path)"""
+"""pymotion.io.bvh.BVH: adapter over dragposer_amd/bvh.py.  Call sites in the reference: train.py:322-326 (load), 329-341 (the
+`data` dictionary: rotations [F, J, 3] degrees in channel order, rot_order [J, 3], positions [F, J, 3], parents (root: None),
+offsets [J, 3]), 476 (get_data), 489-508 (data written back, save)."""
+import numpy as np
+
+from dragposer_amd import quat_np as _Q
+from dragposer_amd.bvh import BVH as _BVH
 
 
 class BVH:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("stand-in: off the hot path")
+    def __init__(self):
+        self._b = None
+        self.data = {}
+
+    def load(self, path):
+        self._b = _BVH().load(path)
+        rot, pos, parents, offsets, order = self._b.get_data()
+        raw_offsets = np.asarray(self._b.offsets, dtype=np.float64).copy()  # (the root's as the file has it; the reference zeroes it itself)
+        self.data = dict(names=list(self._b.names), rotations=rot, positions=pos, offsets=raw_offsets,
+                         parents=[None] + [int(p) for p in self._b.parents[1:]],
+                         rot_order=np.array([list(o) for o in order]), frame_time=self._b.frame_time)
+        return self
+
+    def get_data(self):
+        """-> local quaternions, local positions, parents, offsets, end sites, end-site parents (train.py:476 unpacks six)"""
+        order = ["".join(o) for o in self.data["rot_order"]]
+        rot = self.data["rotations"]
+        q = np.stack([_Q.from_euler(np.radians(rot[:, j]), order[j]) for j in range(rot.shape[1])], axis=1)
+        return q, self.data["positions"], self.data["parents"], self.data["offsets"], None, None
+
+    def save(self, path):
+        self._b.set_data(np.asarray(self.data["rotations"], dtype=np.float64), np.asarray(self.data["positions"], dtype=np.float64)[:, 0])
+        self._b.save(path)
