@@ -70,7 +70,7 @@ def synth_on_device(opt, B, seed, device, lo=0, hi=None, mixed=False):
                 w=w, tracked=tracked)
 
 
-PMC_FILE = "profiles/r03_pmc_per_launch.json"
+PMC_FILE = "profiles/r04_pmc_per_launch.json"
 
 
 def pmc_traffic_bytes(frames, iters):
@@ -83,6 +83,58 @@ def pmc_traffic_bytes(frames, iters):
     with open(path) as f:
         c = json.load(f)
     return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+
+
+def measure_traffic(argv_tail, kernel_substr):
+    """HBM bytes per launch of the dominant kernel MEASURED BY THIS COMMAND: two child runs of this very script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (the TCC counters do not fit one pass; the program directly after
+    `--`), same workload, 6 launches each; counters summed over the XCDs per dispatch, averaged over the full-size launches (the
+    first dispatch of the kernel is the forward-only launch that makes the synthetic targets).  Corrected as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE x 2 (gfx950 tallies 128-byte read requests at 64 bytes), both in KB.  Called BEFORE this process touches
+    the GPU (a process that has initialised HIP must not start other programs).  Returns (bytes, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import Counter, defaultdict
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    work = tempfile.mkdtemp(prefix="dp_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--traffic", "none"] + argv_tail
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            per = defaultdict(float)
+            rows = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                rows += [x for x in csv.DictReader(open(path)) if kernel_substr in x["Kernel_Name"] and x["Counter_Name"] == counter]
+            if not rows:
+                return None, f"no {counter} rows for {kernel_substr}"
+            grid = Counter(x["Grid_Size"] for x in rows).most_common(1)[0][0]
+            first = min(int(x["Dispatch_Id"]) for x in rows)
+            for x in rows:
+                if x["Grid_Size"] == grid and int(x["Dispatch_Id"]) != first:
+                    per[x["Dispatch_Id"]] += float(x["Counter_Value"])
+            if not per:
+                return None, f"no full-size dispatch in the {counter} pass"
+            got[counter] = (sum(per.values()) / len(per), len(per))
+    except Exception as e:  # (a profiler that is absent, refused or broken must not take the benchmark down)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    note = (f"measured by this command: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same workload as child processes "
+            f"(means over {got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches); bytes = 2 x FETCH_SIZE (gfx950 read under-count) + WRITE_SIZE, both KB "
+            f"-> {got['FETCH_SIZE'][0]:.1f} KB fetched (uncorrected), {got['WRITE_SIZE'][0]:.1f} KB written")
+    return (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, note
 
 
 def cpu_baseline(batch_np, n_iter, budget_s=20.0):
@@ -134,6 +186,9 @@ def main():
     ap.add_argument("--config", default="s1", choices=["s1", "s4"],
                     help="s1: BASELINE's headline workload (6 trackers, fp32); s4: BASELINE config 5 (1-6 trackers per frame, bf16-rounded decoder weights)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "w4", "w16"], help="include/dragposer.h: DP_KERNEL_*")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
+                    help="roofline.traffic: measure = two rocprofv3 --pmc child passes of this workload (N = 1 only, adds about a minute); file = the committed "
+                         "PMC passes (profiles/); auto = measure when rocprofv3 is there and N = 1, else file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -145,6 +200,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    traffic, traffic_note = None, None
+    if world == 1 and args.traffic in ("auto", "measure"):  # before anything touches the GPU in this process
+        tail = ["--frames", str(args.frames), "--iters", str(args.iters), "--config", args.config, "--kernel", args.kernel]
+        if args.total_frames > 0:
+            tail += ["--total-frames", str(args.total_frames)]
+        traffic, traffic_note = measure_traffic(tail, "dp_w")
+        if traffic is None:
+            print(f"[bench] HBM traffic not measured ({traffic_note}); falling back to the committed PMC passes", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product has no CPU path")
     if args.all_ranks_on_device0:
@@ -248,9 +311,11 @@ def main():
                        "frames_per_gpu": Bk, "frames_total": total_per_step, "iters": N,
                        "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA, "traffic": pmc_traffic_bytes(Bk, N),
-                         "traffic_note": f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes "
-                                         f"({PMC_FILE}, same command); algorithmic {Bk * 2326:.3g}",
+                         "frac": achieved / PEAK_F32_MFMA,
+                         "traffic": traffic if traffic is not None else (pmc_traffic_bytes(Bk, N) if args.traffic != "none" else None),
+                         "traffic_note": (traffic_note if traffic is not None else
+                                          f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes ({PMC_FILE}, same command)")
+                                         + f"; algorithmic {Bk * 2326:.3g}",
                          "kernel": {16: "dp_w4_kernel<4, false>", 64: "dp_w16_kernel<4, 1>", 128: "dp_w16_kernel<8, 2>"}.get(fpb, "?"), "kernel_ms": kern_ms,
                          "frac_of_bf16_mfma_peak_2.5PF": (achieved / 2.5e15 if fpb >= 64 else None),
                          "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},

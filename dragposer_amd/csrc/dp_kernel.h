@@ -65,7 +65,7 @@ extern "C" int dp_kernel_lds_bytes(void);
 extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream);
 extern "C" int dp_w4_lds_bytes(void);
 extern "C" int dp_w4_frames_per_block(void);
-// dp_w16.hip: 16 frames per wave, decoder on v_mfma_f32_16x16x32_bf16 in split precision (fixed iteration count only)
+// dp_w16*.hip: 16 frames per wave, decoder on v_mfma_f32_16x16x32_bf16 in split precision (fixed iteration count, or KArgs.early_stop: the per-frame while-condition)
 extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int waves /* 4 or 8 per workgroup */);
 extern "C" int dp_w16_lds_bytes(void);
 extern "C" int dp_w16_frames_per_wave(void);

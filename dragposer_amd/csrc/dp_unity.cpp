@@ -54,7 +54,6 @@ struct DragPoser {
     bool warned_temporal = false;
     int current_index = 0;   // frame inside the temporal window (drag_pose.py:399-402)
     int target_window = -1;  // window the device target buffer was sized for
-    bool pull_was_on = false; // the temporal term was on in the previous frame
     // state (drag_pose.py:47-64)
     bool initialised = false;
     float latent[LAT] = {0}, cur_pos[3] = {0, 0, 0};
@@ -418,19 +417,19 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     b.n_frames = 1;
     b.z0 = di + IN_Z0; b.z_tgt = di + IN_ZT; b.cur_rot = di + IN_ROT; b.tgt_pos = di + IN_TP; b.tgt_rot = di + IN_TR; b.w = di + IN_W;
     b.tracked = (const unsigned char*)(di + IN_TRK);
-    // temporal target block (drag_pose.py:234-294): a prediction every `window` frames, one row of it per frame
-    // The reference runs its predictor at current_index == 0 whatever lambda_temporal is (drag_pose.py:235-291); a prediction is a
-    // 0.2 ms launch, so this plug-in makes it only while the pull term is on -- and when the term is switched on in the middle of
-    // a window (Unity's SetLambdas) it restarts the window, so that the first pulled frame has a fresh prediction instead of a
-    // stale or zero-filled buffer.
+    // temporal target block (drag_pose.py:234-294): a prediction every `window` frames, one row of it per frame.
+    // The reference's schedule: the buffer is (re)allocated when the window changes (drag_pose.py:238-246) and the predictor runs
+    // whenever current_index == 0 -- WHATEVER lambda_temporal is (drag_pose.py:247-291): with the pull term off the buffer is still
+    // refreshed every `window` frames, so a caller that switches the term on in the middle of a window (Unity's SetLambdas) pulls
+    // towards the prediction made at that window's start.  This plug-in does the same (round 3 predicted only while the term was on
+    // and restarted the window at switch-on: a different z_tgt for up to window - 1 frames; tests/golden/sequ_switch.npz pins the
+    // reference's behaviour).  Where it still departs: a window CHANGED mid-window restarts the window (below).
     const bool have_predictor = d->temporal != nullptr;
     const bool pull = have_predictor && d->lambda_tmp != 0.f;
-    if (pull && !d->pull_was_on) d->current_index = 0;
-    d->pull_was_on = pull;
     dp_seq_state st = seq_state(d);
     // (the sequence's global position / rotation live on the device: reset_device_state, set_global_pos; the staged
     //  cur_rot below is what dp_optimize took and is kept for reference)
-    if (pull) {
+    if (have_predictor) {
         if (d->window < 0) { d->fail("drag_pose: temporalFutureWindow must not be negative"); return; } // (a multiple of the predictor's sample_step: dp_temporal_predict checks)
         if (d->target_window != d->window) { // (re)sized and zeroed, as drag_pose.py:238-246 does
             // Unity's SetLambdas may change the window mid-window.  The reference keeps current_index and then indexes the

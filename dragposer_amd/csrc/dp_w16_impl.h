@@ -1,6 +1,7 @@
 #pragma once
-// dp_w16_impl.h -- (included by dp_w16.hip and dp_w16_2w.hip, one instantiation each: the two are compiled with different
-// instruction-scheduling strategies, __graft_entry__.py)
+// dp_w16_impl.h -- (included by FOUR translation units, one instantiation each -- dp_w16.hip / dp_w16_2w.hip: fixed iteration count,
+// one / two waves per SIMD; dp_w16_es.hip / dp_w16_2w_es.hip: the same two with the reference's per-frame while-condition -- because
+// the one-wave and the two-waves shapes want different instruction-scheduling strategies, __graft_entry__.py)
 // dp_w16 -- the optimise loop (reference: DragPose.run's while loop, python/src/drag_pose.py:296-355) with SIXTEEN frames per
 // wavefront, the decoder on v_mfma_f32_16x16x32_bf16 in split precision (dp_w16.h), for large batches.
 //
@@ -17,7 +18,8 @@
 //     product, gradients as torques.  Every joint slot may carry a tracker; a tile of slots no frame of the wave tracks is skipped.
 //   * bf16 MFMAs leave the vector ALU free (profiles/r03_pair_probe.txt), fp32 MFMAs do not: here the element-wise and kinematics
 //     work of one tile runs under the matrix work of the next.
-// Fixed iteration count only (the per-frame while-condition and forward-only launches stay with dp_w4.hip).
+// Fixed iteration count or, EARLY, the reference's per-frame while-condition; forward-only launches and whole-sequence launches stay
+// with dp_w4.hip.
 #include "dp_device.h"
 #include "dp_w16.h"
 
@@ -111,7 +113,8 @@ DEV f4 mm(u4 a, u4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__b
 
 // The weights of one (output tile, K-block) pair: three ds_read_b128 (the bf16 terms of the same 16 x 32 block).  The 45 pairs of an
 // iteration are consumed in a fixed order, so every pair's reads are ISSUED ONE PAIR AHEAD of its six MFMAs (a lone wave otherwise
-// sits out an LDS round trip per pair: 4.8 k of 16 k cycles per iteration waiting at s_waitcnt, profiles/r03_w16_pmc_first.txt).
+// sits out an LDS round trip per pair: 4.8 k of 16 k cycles per iteration waiting at s_waitcnt before this, 3.2 k after -- DESIGN.md 6.2;
+// the counters of the kernel as it stands: profiles/r03_w16_pmc_16384.txt).
 struct W3 { u4 h, m, l; };
 // The image is 135 KB and a ds_read's offset field holds 16 bits: three lane bases 64 KB apart, each opaque to the compiler (it would
 // fold them back into ONE base and pay a v_add_u32 per read beyond the first 64 KB: 71 per iteration).

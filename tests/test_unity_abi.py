@@ -135,12 +135,9 @@ def _mat_to_quat(M):
     return np.array([w, np.copysign(x, M[2, 1] - M[1, 2]), np.copysign(y, M[0, 2] - M[2, 0]), np.copysign(z, M[1, 0] - M[0, 1])])
 
 
-@pytest.mark.gpu
-def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_dir, tmp_path):
-    """The plugin driven with what the REFERENCE saw and compared with what the reference returned (tests/golden/sequ.npz:
-    the real DragPose.run over one sequence as the Unity path calls it -- run_drag.py:141-157: no joint adjustment, zero
-    initial heights -- with lambda_temporal 0.02, a window of 8 frames and the reference's own Temporal class, whose
-    state_dict becomes the plugin's temporal.bin).  Closed loop: strict over the first 16 frames, as test_hip_sequences."""
+def _drive_plugin(golden_dir, tmp_path, name):
+    """the plug-in fed what the REFERENCE saw in tests/golden/<name>.npz, frame by frame, with the lambda the reference had at that
+    frame (set_lambdas before every drag_pose, as Unity's SetLambdas may); returns per-frame errors against what the reference returned"""
     import shutil
     import sys
 
@@ -149,10 +146,11 @@ def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import export_temporal_bin as X
 
-    g = R.load_golden(os.path.join(golden_dir, "sequ.npz"))
+    g = R.load_golden(os.path.join(golden_dir, f"{name}.npz"))
     cfg, T = g["meta"]["cfg"], g["meta"]["T"]
+    lam = [0.0 if t < cfg.get("lambda_switch_frame", 0) else float(cfg["lambda_temporal"]) for t in range(T)]
     shutil.copy(os.path.join(DATA, "dragposer_model.bin"), tmp_path / "dragposer_model.bin")
-    X.write(X.tensors_from(os.path.join(golden_dir, "sequ.npz")), str(tmp_path / "temporal.bin"))
+    X.write(X.tensors_from(os.path.join(golden_dir, f"{name}.npz")), str(tmp_path / "temporal.bin"))
     lib = _load()
     lib.drag_poser_has_temporal.argtypes = [C.c_void_p]
     h = lib.init_drag_poser()
@@ -165,7 +163,7 @@ def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_
     w[g["mask_idx"]] = g["weights"]
     lib.set_mask_and_weights(h, mask.ctypes.data_as(C.POINTER(C.c_float)), w.ctypes.data_as(C.POINTER(F2)))
     lib.set_optim_params(h, 0.01 * 0.01, 0.01, 100, 1e-2)
-    lib.set_lambdas(h, 1.0, float(cfg["lambda_temporal"]), int(cfg["temporal_future_window"]))
+    lib.set_lambdas(h, 1.0, lam[0], int(cfg["temporal_future_window"]))
     assert lib.drag_poser_last_error(h) == b""  # a predictor is loaded: nothing to report
     lib.init_drag_model(h, F3(0.0, 0.0, 0.0), Qt(*[float(v) for v in g["init_rot"][0]]))
     z0 = np.ascontiguousarray(g["z0"][0], np.float32)
@@ -175,6 +173,7 @@ def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_
     E = len(g["mask_idx"])
     gpos_mm, iters_equal, z_err, q_err = [], [], [], []
     for t in range(T):
+        lib.set_lambdas(h, 1.0, lam[t], int(cfg["temporal_future_window"]))
         tp, tq = g["tgt_pos"][t, 0], np.stack([_mat_to_quat(M.astype(np.float64)) for M in g["tgt_rot"][t, 0]])
         res_pose, res_pos = (Qt * 22)(), (F3 * 1)()
         lib.drag_pose(h, E, (F3 * E)(*[F3(*map(float, p)) for p in tp]), (Qt * E)(*[Qt(*map(float, q)) for q in tq]), res_pose, res_pos)
@@ -186,7 +185,16 @@ def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_
         z_err.append(np.abs(z - g["latent"][t, 0]).max())
         want = Q.from_root_space((g["pose_ret"][t, 0].astype(np.float64) * std_q + mean_q).reshape(1, 22, 4), raw["parents"])[0]
         q_err.append(np.abs(np.array([[q.w, q.x, q.y, q.z] for q in res_pose]) - want).max())
-    gpos_mm, iters_equal, z_err, q_err = map(np.array, (gpos_mm, iters_equal, z_err, q_err))
+    return lib, h, g, z0, E, lam, tuple(map(np.array, (gpos_mm, iters_equal, z_err, q_err)))
+
+
+@pytest.mark.gpu
+def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_dir, tmp_path):
+    """The plugin driven with what the REFERENCE saw and compared with what the reference returned (tests/golden/sequ.npz:
+    the real DragPose.run over one sequence as the Unity path calls it -- run_drag.py:141-157: no joint adjustment, zero
+    initial heights -- with lambda_temporal 0.02, a window of 8 frames and the reference's own Temporal class, whose
+    state_dict becomes the plugin's temporal.bin).  Closed loop: strict over the first 16 frames, as test_hip_sequences."""
+    lib, h, g, z0, E, lam, (gpos_mm, iters_equal, z_err, q_err) = _drive_plugin(golden_dir, tmp_path, "sequ")
     print(f"plugin vs reference (sequ): gpos {gpos_mm[:16].max():.4f} mm (all {gpos_mm.max():.4f}), latent {z_err[:16].max():.2e}, "
           f"local quaternions {q_err[:16].max():.2e}, same iteration count on {iters_equal.mean():.0%} of the frames")
     assert iters_equal[:16].mean() >= 0.95 and gpos_mm[:16].max() <= 0.02 and z_err[:16].max() <= 5e-4 and q_err[:16].max() <= 1e-4
@@ -201,4 +209,21 @@ def test_plugin_reproduces_the_reference_sequence_with_the_temporal_term(golden_
     z = np.zeros(24, np.float32)
     lib.drag_poser_get_latent(h, z.ctypes.data_as(C.POINTER(C.c_float)))
     assert np.abs(z - g["latent"][3, 0]).max() > 10 * z_err[3]
+    lib.destroy_drag_poser(h)
+
+
+@pytest.mark.gpu
+def test_plugin_follows_the_references_predictor_schedule_when_the_term_is_switched_on_mid_window(golden_dir, tmp_path):
+    """tests/golden/sequ_switch.npz: the reference's DragPose.run over the same kind of sequence with lambda_temporal = 0 for the first
+    11 frames and 0.02 from frame 11 -- the fourth frame of the second window of 8.  The reference predicts at every window start
+    whatever lambda is (drag_pose.py:247-291), so frames 11..15 pull towards the prediction made at frame 8, from the history as it
+    stood then.  A plug-in that predicts only while the term is on (round 3: it restarted the window at switch-on and predicted from
+    frame 11's history) gives another z_tgt for those frames; this one must give the reference's."""
+    lib, h, g, z0, E, lam, (gpos_mm, iters_equal, z_err, q_err) = _drive_plugin(golden_dir, tmp_path, "sequ_switch")
+    sw = g["meta"]["cfg"]["lambda_switch_frame"]
+    assert lam[sw - 1] == 0.0 and lam[sw] > 0.0 and sw % g["meta"]["cfg"]["temporal_future_window"] != 0
+    print(f"plugin vs reference (sequ_switch, term on from frame {sw}): gpos {gpos_mm[:16].max():.4f} mm (all {gpos_mm.max():.4f}), latent before the switch "
+          f"{z_err[:sw].max():.2e}, frames {sw}..15 {z_err[sw:16].max():.2e}, local quaternions {q_err[:16].max():.2e}, same iteration count on "
+          f"{iters_equal.mean():.0%} of the frames (reference: {g['iters'][:, 0].tolist()})")
+    assert iters_equal[:16].mean() >= 0.9 and gpos_mm[:16].max() <= 0.05 and z_err[:16].max() <= 1e-3 and q_err[:16].max() <= 2e-4
     lib.destroy_drag_poser(h)

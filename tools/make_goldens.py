@@ -549,10 +549,12 @@ def run_sequences(name, K, T, cfg, offsets_t, parents, seed):
             n0 = len(drag.rec)
             ci = drag.current_index
             ja = tuple(cfg["joint_adjustment_indices"]) if cfg["enable_joint_adjustment"] else None
+            # "lambda_switch_frame": the pull term is off before that frame and on from it (Unity's SetLambdas in the middle of a window)
+            lam_t = 0.0 if t < cfg.get("lambda_switch_frame", 0) else cfg["lambda_temporal"]
             pose_ret, gpos_ret = drag.run(
                 target_ee_pos=tp, target_ee_rot=tR, mask_joints=idx, weights_joints=wj, offsets=offsets_t,
                 stop_eps_pos=0.01 * 0.01, stop_eps_rot=0.01, max_iter=100, min_loss_incr=0.00001, learning_rate=1e-2,
-                lambda_rot=1, lambda_temporal=cfg["lambda_temporal"], temporal_future_window=cfg["temporal_future_window"],
+                lambda_rot=1, lambda_temporal=lam_t, temporal_future_window=cfg["temporal_future_window"],
                 height_indices=height_idx, joint_adjustment_indices=ja, joint_adjustment_weight=cfg["joint_adjustment_weight"],
                 verbose=False)
             out["tgt_pos"][t, k], out["tgt_rot"][t, k] = tp.numpy(), tR.numpy()
@@ -632,7 +634,10 @@ def main():
     # "sequ": the shape of the Unity path (run_drag.py:141-157): one sequence, no joint adjustment, zero initial heights,
     # the temporal term on with a window that takes several autoregressive calls
     cfgu = dict(cfg6, enable_joint_adjustment=False, lambda_temporal=0.02, temporal_future_window=8, unity_initial_heights=True)
-    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78), ("sequ", cfgu, 1, 24, 79)):
+    # "sequ_switch": the same shape with the pull term switched on at frame 11 -- the fourth frame of the second window of 8: the
+    # reference has been predicting at every window start all along (drag_pose.py:247-291 does not look at lambda_temporal)
+    cfgs = dict(cfgu, lambda_switch_frame=11)
+    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78), ("sequ", cfgu, 1, 24, 79), ("sequ_switch", cfgs, 1, 24, 80)):
         if name in todo:
             out = run_sequences(name, K, T, cfg, offsets_t, parents, seed)
             path = os.path.join(gold, f"{name}.npz")
