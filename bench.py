@@ -201,6 +201,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     traffic, traffic_note = None, None
+    under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if args.traffic == "auto" and under_profiler:
+        args.traffic = "file"  # (this process is itself being profiled: no profiler inside the profiler)
     if world == 1 and args.traffic in ("auto", "measure"):  # before anything touches the GPU in this process
         tail = ["--frames", str(args.frames), "--iters", str(args.iters), "--config", args.config, "--kernel", args.kernel]
         if args.total_frames > 0:

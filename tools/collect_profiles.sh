@@ -1,12 +1,12 @@
 #!/bin/bash
-# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r03/).
+# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r04/).
 # rocprofv3: program directly after `--`; counters in their own passes with --kernel-trace only.
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/prof_r03
+O=gpurun_out/prof_r04
 rm -rf $O && mkdir -p $O
 # 1. kernel-trace stats of the default bench command
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --no-cpu-baseline --traffic file > $O/bench_under_rocprof.json 2> $O/stats.log
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 echo "stats done"
 # 2. PMC passes
@@ -14,7 +14,7 @@ i=0
 for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_F32" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   # (TCC budget: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ: at most 8 per pass)
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$i --output-format csv -- python3 bench.py --steps 10 --no-cpu-baseline --no-parity > $O/pmc$i.log 2>&1 || { echo "pass $i ($grp) failed"; tail -5 $O/pmc$i.log; exit 1; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$i --output-format csv -- python3 bench.py --steps 10 --no-cpu-baseline --no-parity --traffic none > $O/pmc$i.log 2>&1 || { echo "pass $i ($grp) failed"; tail -5 $O/pmc$i.log; exit 1; }
   echo "pmc pass $i done"
 done
 python3 tools/pmc_summary.py $O/pmc_per_launch.json $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 $O/pmc6 $O/pmc7 > /dev/null
@@ -22,7 +22,7 @@ python3 tools/pmc_summary.py $O/pmc_per_launch.json $O/pmc1 $O/pmc2 $O/pmc3 $O/p
 # (the library's own kernel choice: dp_w4 up to 4096 frames, dp_w16 beyond; then dp_w4 forced at the large sizes for comparison)
 for spec in 256:auto 1024:auto 2048:auto 4096:auto 6144:auto 8192:auto 16384:auto 65536:auto 6144:w4 8192:w4 16384:w4 65536:w4; do
   fr=${spec%%:*}; kn=${spec##*:}
-  python3 bench.py --frames $fr --kernel $kn --steps 20 --warmup 3 --no-cpu-baseline --no-parity | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '--kernel $kn:', '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
+  python3 bench.py --frames $fr --kernel $kn --steps 20 --warmup 3 --no-cpu-baseline --no-parity --traffic none | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '--kernel $kn:', '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
 done > $O/batch_sweep.txt
 echo "sweep done"
 # 4. phase stamps (diagnostic build): the product's kernel, and the previous decomposition for comparison
@@ -43,9 +43,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tstats --output-format 
 grep "dp_temporal_kernel\|\"Name\"" $(find $O/tstats -name "*kernel_stats.csv" | head -1) > $O/temporal_kernel_stats.csv
 echo "temporal done"
 # 8. the 16-frames-per-wave kernel: BASELINE config 5 through bench.py (the JSON line), kernel trace, batch sweep of both kernels, PMC passes
-python3 bench.py --config s4 --frames 16384 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_s4_16384.json 2> /dev/null
-python3 bench.py --config s4 --frames 65536 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_s4_65536.json 2> /dev/null
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/s4stats --output-format csv -- python3 bench.py --config s4 --frames 16384 --steps 20 --no-cpu-baseline > $O/bench_s4_under_rocprof.json 2> $O/s4stats.log
+python3 bench.py --config s4 --frames 16384 --steps 20 --warmup 3 --no-cpu-baseline --traffic none > $O/bench_s4_16384.json 2> /dev/null
+python3 bench.py --config s4 --frames 65536 --steps 10 --warmup 2 --no-cpu-baseline --traffic none > $O/bench_s4_65536.json 2> /dev/null
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/s4stats --output-format csv -- python3 bench.py --config s4 --frames 16384 --steps 20 --no-cpu-baseline --traffic none > $O/bench_s4_under_rocprof.json 2> $O/s4stats.log
 grep "dp_w16_kernel\|dp_w4_kernel\|\"Name\"" $(find $O/s4stats -name "*kernel_stats.csv" | head -1) > $O/bench_s4_kernel_stats.csv
 python3 tools/w16_sweep.py 4096 5120 6144 8192 16384 32768 65536 131072 > $O/w16_sweep.txt 2>&1
 bash tools/w16_pmc.sh 16384 $O/w16_pmc_16384 > $O/w16_pmc_16384.txt 2>&1
@@ -63,4 +63,10 @@ python3 bench.py > $O/bench_default.json 2> /dev/null
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 python3 -m pytest tests -q -m gpu -s 2>&1 | grep -v "amdgpu.ids\|Warning\|warnings.warn\|self.encoder" > $O/gpu_tests_log.txt || true
 echo "bench + tests done"
+# 11. round 4: the cooperative-shape probe, where the at-size misses start, the closed loop's sensitivity
+tools/ubench/bin/coop_probe 256 58 > $O/coop_probe.txt 2>&1 || true
+python3 tools/frame_divergence.py full_s4_1024 w16 962,502 2>&1 | grep -v amdgpu.ids > $O/divergence_s4.txt || true
+python3 tools/frame_divergence.py full_s3_1024 w16 316,651,746,870 2>&1 | grep -v amdgpu.ids > $O/divergence_s3.txt || true
+python3 tools/temporal_divergence.py 2>&1 | grep -v "amdgpu.ids\|Warning\|self.encoder\|^Frame:" > $O/temporal_divergence.txt || true
+echo "round-4 probes done"
 ls $O
