@@ -77,13 +77,24 @@ template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE
 // reads its B operand from either half; the kinematics arithmetic cannot use that half anyway), streamed weights and the
 // accumulators in the vector half.  Hazards the compiler would pad for a builtin: a dependent accumulate (SrcC) needs 2
 // wait states behind a 2-pass MFMA -> the s_nop between the pairs; the readers of the result: chain_end().
+// W4_TAIL: what stands behind a group's last pair.  The next statement's first MFMA accumulates into acc0 again: M3(acc0) M4(acc1) | M1'(acc0)
+// needs two wait states between M3 and M1' -- M4 and ONE more.  hipcc puts an `s_nop 0` of its own between any two asm statements, and
+// that one is the second wait state: a nop of ours on top of it (rounds 2 and 3 had one) is a THIRD, and two back-to-back nops are not
+// hidden behind the 8-cycle MFMA -- 4 cycles per group of four, 99 groups per iteration: dropping it measured -3.8 % kernel time
+// (0.1614 -> 0.1553 ms, A/B inside one gpurun call, outputs bit-identical).  The compiler's nop is not ours to rely on blindly:
+// tools/check_mfma_hazards.py walks the generated ISA and tests/test_build_quality.py fails if any dependent pair ends up closer
+// than two wait states.  -DW4_TRAIL_NOP restores the belt-and-braces form.
+#ifdef W4_TRAIL_NOP
+#define W4_TAIL "\n\ts_nop 0"
+#else
+#define W4_TAIL ""
+#endif
 #define W4_GROUP_ASM(WC)                                                                                                  \
     asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"                                           \
                  "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%10\n\t"                                           \
                  "s_nop 0\n\t"                                                                                           \
                  "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"                                           \
-                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"                                           \
-                 "s_nop 0"                                                                                                \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10" W4_TAIL                                                  \
                  : "+v"(acc0), "+v"(acc1)                                                                                 \
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
 // the same with CBSZ = 3 (two K-steps per instruction, dp_w4.h), weights in vector registers, starting from zero or not
@@ -92,8 +103,7 @@ template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE
                  "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, " C1 " cbsz:3 abid:%10\n\t"                                       \
                  "s_nop 0\n\t"                                                                                           \
                  "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:3 abid:%10\n\t"                                           \
-                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:3 abid:%10\n\t"                                           \
-                 "s_nop 0"                                                                                                \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:3 abid:%10" W4_TAIL                                                  \
                  : OUT(acc0), OUT(acc1)                                                                                   \
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(ABID))
 template <int ABID> DEV void group3_v(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_GROUP3_ASM("%0", "%1", "+v"); }
@@ -107,8 +117,7 @@ template <int ABID> DEV void group_v(f4& acc0, f4& acc1, const f4& x, const f4& 
                  "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, 0 cbsz:4 abid:%10\n\t"                                            \
                  "s_nop 0\n\t"                                                                                           \
                  "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"                                           \
-                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"                                           \
-                 "s_nop 0"                                                                                                \
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10" W4_TAIL                                                  \
                  : OUT0(acc0), "=&v"(acc1)                                                                                \
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), WC(w[0]), WC(w[1]), WC(w[2]), WC(w[3]), "i"(ABID))
 // ... or a bias row: C = a register tuple that holds it for the whole launch, D = the accumulator (no copy per iteration)
@@ -118,16 +127,20 @@ template <int ABID> DEV void first_a_biased(f4& acc0, f4& acc1, const f4& x, con
                  "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, 0 cbsz:4 abid:%10\n\t"
                  "s_nop 0\n\t"
                  "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"
-                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"
-                 "s_nop 0"
+                 "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10" W4_TAIL
                  : "=&v"(acc0), "=&v"(acc1)
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "a"(w[0]), "a"(w[1]), "a"(w[2]), "a"(w[3]), "i"(ABID), "v"(c));
 }
 template <int ABID> DEV void first_a_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("a", "0", "=&v"); }
 template <int ABID> DEV void first_v_zero(f4& acc0, f4& acc1, const f4& x, const f4& w) { W4_FIRST_ASM("v", "0", "=&v"); }
 // a VALU result (transpose, kinematics) feeding the first MFMA of a chain / the chain's result feeding the VALU
-DEV void chain_begin() { asm volatile("s_nop 1"); }
-DEV void chain_end(f4& acc0, f4& acc1) { asm volatile("s_nop 3" : "+v"(acc0), "+v"(acc1)); }
+// (needed: VALU -> MFMA operand 2 wait states, MFMA -> MFMA operand 4 -- what hipcc itself pads builtins with.  Behind a transpose
+//  nothing is missing: its own `s_nop 3` and the `s_nop 0` hipcc puts between two asm statements make 5.  Behind VALU code this
+//  statement's one wait state and that same compiler nop make 2.  tools/check_mfma_hazards.py holds the generated ISA to all of it.)
+DEV void chain_begin() { asm volatile("s_nop 0"); }
+// chain_end: MFMA -> VALU read needs 4 wait states; hipcc adds one `s_nop 0` of its own behind an asm statement whose outputs the next
+// instructions read (seen in every build; tools/check_mfma_hazards.py fails the build-quality test if it ever does not), so three here.
+DEV void chain_end(f4& acc0, f4& acc1) { asm volatile("s_nop 2" : "+v"(acc0), "+v"(acc1)); }
 
 // NG groups from resident weights (accumulator registers) / from weights in vector registers
 // START: 0 continues a chain; 1 starts one from the bias row `bias`; 2 starts one from zero
@@ -180,10 +193,20 @@ template <int NG> DEV void touch_v(f4* wv) { static_for<NG>([&](auto gi) { touch
 // e_r[j] = (j == r) -- products with 1, sums with 0: exact.  Four dependent 2-pass MFMAs; the result may feed an MFMA
 // (4 wait states) or the VALU (4).  (The VALU form -- two exchange stages of v_cndmask_b32_dpp -- is in
 // tools/ubench/w4_probe.hip; it measured 1.3 % slower in the loop and keeps the VALU busy between two products.)
+// Head and tail of a transpose: its input comes from VALU code (2 wait states), its result feeds an MFMA chain or the VALU (4).  In every
+// build hipcc puts an `s_nop 0` in front of and behind these statements (rounds 2 and 3 added `s_nop 1` / `s_nop 3` of their own on top:
+// 3 and 5 wait states); one fewer of ours each, the generated ISA held to the requirement by tools/check_mfma_hazards.py.
+#ifdef W4_TRAIL_NOP
+#define W4_QT_HEAD "s_nop 1\n\t"
+#define W4_QT_TAIL "s_nop 3"
+#else
+#define W4_QT_HEAD "s_nop 0\n\t"
+#define W4_QT_TAIL "s_nop 2"
+#endif
 DEV void quad_transpose_mfma(f4& r, const f4& e)
 {
     f4 d;
-    asm volatile("s_nop 1\n\t"
+    asm volatile(W4_QT_HEAD
                  "v_mfma_f32_4x4x1_16b_f32 %0, %1, %5, 0\n\t"
                  "s_nop 1\n\t"
                  "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0\n\t"
@@ -191,7 +214,7 @@ DEV void quad_transpose_mfma(f4& r, const f4& e)
                  "v_mfma_f32_4x4x1_16b_f32 %0, %3, %7, %0\n\t"
                  "s_nop 1\n\t"
                  "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
-                 "s_nop 3"
+                 W4_QT_TAIL
                  : "=&v"(d)
                  : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
     r = d;
@@ -202,7 +225,7 @@ DEV void quad_transpose_mfma(f4& r, const f4& e)
 DEV void quad_transpose_mfma2(f4& r0, f4& r1, const f4& e)
 {
     f4 d0, d1;
-    asm volatile("s_nop 1\n\t"
+    asm volatile(W4_QT_HEAD
                  "v_mfma_f32_4x4x1_16b_f32 %0, %2, %10, 0\n\t"
                  "v_mfma_f32_4x4x1_16b_f32 %1, %6, %10, 0\n\t"
                  "s_nop 0\n\t"
@@ -214,7 +237,7 @@ DEV void quad_transpose_mfma2(f4& r0, f4& r1, const f4& e)
                  "s_nop 0\n\t"
                  "v_mfma_f32_4x4x1_16b_f32 %0, %5, %13, %0\n\t"
                  "v_mfma_f32_4x4x1_16b_f32 %1, %9, %13, %1\n\t"
-                 "s_nop 3"
+                 W4_QT_TAIL
                  : "=&v"(d0), "=&v"(d1)
                  : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]), "v"(e[0]), "v"(e[1]),
                    "v"(e[2]), "v"(e[3]));
@@ -555,6 +578,9 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
 #pragma unroll
         for (int u = 0; u < 6; ++u) g[u] = *(const f4*)(tab + 4 * u);
 #pragma unroll
+        for (int u = 0; u < 6; ++u) asm volatile("" : "+v"(g[u])); // (keeps the reads 16 bytes wide: the fourth word is unused, and hipcc would
+                                                                    //  narrow them to ds_read_b96 -- 8 LDS cycles in 8-lane groups against ds_read_b128's 4)
+#pragma unroll
         for (int u = 0; u < 6; ++u) { S[0] += c.sel[u] * splat2(g[u].x); S[1] += c.sel[u] * splat2(g[u].y); S[2] += c.sel[u] * splat2(g[u].z); }
         if (Emax > 6) { // more than 6 trackers in a frame of this wave (uniform, rare): general path
             unsigned m = tmask;
@@ -569,7 +595,8 @@ DEV void g_stage(const PairC& c, const float* fb, const JOut& j, unsigned tmask,
             }
         }
     }
-    const f4 wa = *(const f4*)(fb + c.wtA), wb = *(const f4*)(fb + c.wtB);
+    f4 wa = *(const f4*)(fb + c.wtA), wb = *(const f4*)(fb + c.wtB);
+    asm volatile("" : "+v"(wa), "+v"(wb)); // (16-byte reads, as above)
     // torque: bone x S (+ own rotation torque); on the root the sum over the trackers' root torques itself
     f2 t0 = j.u[1] * S[2] - j.u[2] * S[1] + c.rho * S[0];
     f2 t1 = j.u[2] * S[0] - j.u[0] * S[2] + c.rho * S[1];
@@ -986,7 +1013,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         f4 x = zD;
         QT(x);
         f4 acc0, acc1;
-        chain_begin();
         chain_a<6, 0, 1>(acc0, acc1, x, wL0, bias0T);
         chain_end(acc0, acc1);
         const f4 f0D = lrelu_factor(acc0 + acc1); // kept for the backward
@@ -994,7 +1020,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         // ================= L1: a1 = lrelu(A1 a0 + b1)
         x = (acc0 + acc1) * f0D;
         QT(x);
-        chain_begin();
         chain_a<5, 0, 1>(acc0, acc1, x, wL1, bias1T); // the hidden layer's channels 0..19: quads 0..4,
         chain_a<5, 8>(acc0, acc1, x, wL1 + 5);  // 20..39: quads 8..12 (dp_w4.h)
         chain_end(acc0, acc1);
@@ -1006,7 +1031,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         f4 y01, y23;
         {
             f4 pa0, pa1, pb0, pb1;
-            chain_begin();
             chain_a<15, 0, 1>(pa0, pa1, x, wL2A, bias2aT);
             chain_a<15, 0, 1>(pb0, pb1, x, wL2B, bias2bT);
             chain_end(pa0, pa1);
@@ -1091,14 +1115,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         QT(x);
         STAMP(6);
         // ================= bL1: d0 = (A1^T d1) * lrelu'(a0)
-        chain_begin();
         chain_a<15, 0, 2>(acc0, acc1, x, wB1);
         chain_end(acc0, acc1);
         x = (acc0 + acc1) * f0D;
         QT(x);
         STAMP(7);
         // ================= bL0 + Adam (torch.optim.Adam, single-tensor form; m, v start at 0, t = iter + 1)
-        chain_begin();
         chain3_v_zero<5>(acc0, acc1, x, wz); // two K-steps per instruction: lanes 0..31 | 32..63 hold the two halves of the sum
         chain_end(acc0, acc1);
         __builtin_amdgcn_sched_barrier(0); // (keeps the subtraction below out of the chains above: w4_probe, "independent v_pk_fma")

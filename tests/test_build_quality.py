@@ -93,3 +93,14 @@ def test_w16_instantiations_keep_their_register_budget(tmp_path, src, one_wave):
         assert n["vgpr"] <= 256 and n["vspill"] <= 72, (name, n)
     text = out.read_text()
     assert "v_pk_fma_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text
+
+
+def test_hand_written_mfma_groups_keep_their_wait_states():
+    """dp_w4.hip's MFMA groups are inline asm: the hazard between an MFMA and a later one that accumulates into its result (two wait
+    states for the 2-pass 4x4x1) is the source's responsibility -- and since round 4 one of the two is the `s_nop 0` hipcc itself puts
+    between two asm statements (dp_w4.hip: W4_TAIL).  tools/check_mfma_hazards.py walks the generated ISA of all three instantiations."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_mfma_hazards as H
+
+    n_mfma, counts, bad = H.check(H.isa([]))
+    assert n_mfma == 3 * 396 and counts["C"] > 1000 and counts["AB"] >= 15 and counts["R"] >= 30 and not bad, (n_mfma, counts, bad[:5])
