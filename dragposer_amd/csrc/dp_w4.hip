@@ -219,7 +219,11 @@ DEV void quad_transpose_mfma(f4& r, const f4& e)
                  : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
     r = d;
 }
+#ifdef W4_ABLATE_QT
+#define QT(x) asm volatile("s_nop 1" : "+v"(x))
+#else
 #define QT(x) quad_transpose_mfma(x, eT)
+#endif
 // two independent transposes, their dependent chains interleaved (a dependent 2-pass MFMA needs 2 wait states: the other
 // chain's MFMA and one s_nop)
 DEV void quad_transpose_mfma2(f4& r0, f4& r1, const f4& e)
@@ -1042,12 +1046,19 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         STAMP(2);
 
         // ================= kinematics
+#ifndef W4_ABLATE_J
         j_stage(pc, fb, y01, y23, jo);
+#else
+        jo.q[0] = f2{y01[0], y01[1]}; jo.q[1] = f2{y01[2], y01[3]}; jo.q[2] = f2{y23[0], y23[1]}; jo.q[3] = f2{y23[2], y23[3]};
+        jo.u[0] = jo.q[0]; jo.u[1] = jo.q[1]; jo.u[2] = jo.q[2]; jo.inv = splat2(1.f);
+#endif
         wave_sync();
         STAMP(3);
         if (!optimise) break; // forward-only launch (uniform)
+#ifndef W4_ABLATE_T // (diagnostic builds, tools/ablate_w4.sh: a stage left out to time the rest -- results are wrong by construction)
         t_stage(trk, fb, EARLY || last);
         for (int base = 16; base < Emax; base += 16) t_stage(load_tracker(a, fb, E, base + b), fb, EARLY || last); // (uniform, rare)
+#endif
         // bL2's weights leave LDS in three chunks (a read costs the wave its issue time wherever it stands -- the four waves of
         // a workgroup want the same LDS cycles -- so the chunks only have to be requested a phase ahead of their use, and be
         // small enough for the register file): the rest of the first 8 groups across stage G, 8 ahead of the chain, 10 behind its first chunk (each
@@ -1095,7 +1106,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             stopmask = (unsigned)__ballot(stop_now && b == 0) & 0xFu;
         }
         f4 gyA, gyB;
+#ifndef W4_ABLATE_G
         g_stage(pc, fb, jo, tmask, Emax, gyA, gyB);
+#else
+        gyA = f4{jo.q[0].x, jo.q[1].x, jo.q[2].x, jo.q[3].x}; gyB = f4{jo.q[0].y, jo.q[1].y, jo.q[2].y, jo.q[3].y};
+#endif
         STAMP(5);
 
         // ================= bL2: d1 = (A2^T gy) * lrelu'(a1): K = 4 channels of the 16 side-A items (gyA), then of side-B
@@ -1131,6 +1146,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             for (int r = 0; r < FPW; ++r)
                 if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + lane] = g[r];
         }
+#ifdef W4_ABLATE_ADAM
+        zD = zD - 1e-6f * g;
+#else
         if (!EARLY) {
             if (last && lane < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
 #pragma unroll
@@ -1163,6 +1181,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                 }
             }
         }
+#endif
         STAMP(9);
 #ifdef DP_PROFILE
         if (iter == 0) prof.t[18] = prof.prev - mt0;               // the first iteration (cold instruction cache)
