@@ -110,7 +110,7 @@ def measure_traffic(argv_tail, kernel_substr):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--traffic", "none"] + argv_tail
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
             per = defaultdict(float)
