@@ -113,7 +113,7 @@ class DpResult(C.Structure):
 # every symbol include/dragposer.h declares (checked by tests/test_abi.py)
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
-    "dp_forward", "dp_sequence_advance", "dp_optimize_sequence", "dp_kernel_geometry", "dp_auto_kernel", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync",
+    "dp_forward", "dp_sequence_advance", "dp_optimize_sequence", "dp_kernel_geometry", "dp_auto_kernel", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync", "dp_io_alloc_host", "dp_io_free_host",
     "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict",
 )
 

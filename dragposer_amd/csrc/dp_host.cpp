@@ -532,6 +532,23 @@ extern "C" int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, 
     return DP_OK;
 }
 
+extern "C" int dp_io_alloc_host(dp_ctx* ctx, unsigned long long bytes, void** host_ptr)
+{
+    if (!ctx || !host_ptr) return DP_ERR_INVALID;
+    DEVICE_GUARD(ctx);
+    HIP_TRY(ctx, hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    std::memset(*host_ptr, 0, bytes);
+    return DP_OK;
+}
+
+extern "C" int dp_io_free_host(dp_ctx* ctx, void* host_ptr)
+{
+    if (!ctx) return DP_ERR_INVALID;
+    DEVICE_GUARD(ctx);
+    HIP_TRY(ctx, hipHostFree(host_ptr));
+    return DP_OK;
+}
+
 extern "C" int dp_stream_sync(dp_ctx* ctx, void* stream)
 {
     if (!ctx) return DP_ERR_INVALID;

@@ -62,6 +62,8 @@ struct DragPoser {
     // device staging: one input block, one output block
     void* d_in = nullptr;
     void* d_out = nullptr;
+    float* h_in = nullptr;   // page-locked staging for a frame's inputs / results (dp_io_alloc_host): the two copies of a frame are
+    float* h_out = nullptr;  // asynchronous DMAs instead of blocking copies through the runtime's staging buffer
     // device state of the sequence (drag_pose.py:47-64): global position / rotation and the three 60-frame history
     // buffers, advanced by dp_sequence_advance; the temporal target buffer [window + 1][24]
     void* d_state = nullptr;
@@ -309,6 +311,7 @@ void load_models(DragPoser* d, char* modelPath)
     m.weight_dtype = DP_WEIGHTS_FP32;
     if (d->ctx) { // loaded before: release the previous context and its device buffers
         for (void** p : {&d->d_in, &d->d_out, &d->d_state, &d->d_target}) { if (*p) dp_io_free(d->ctx, *p); *p = nullptr; }
+        for (float** p : {&d->h_in, &d->h_out}) { if (*p) dp_io_free_host(d->ctx, *p); *p = nullptr; }
         if (d->temporal) dp_temporal_destroy(d->temporal);
         d->temporal = nullptr;
         d->target_window = -1;
@@ -320,7 +323,8 @@ void load_models(DragPoser* d, char* modelPath)
         d->current_index = 0;
     }
     if (dp_create(&d->ctx, &m, 0) != DP_OK) { d->fail(std::string("dp_create: ") + dp_last_error(nullptr)); return; }
-    if (dp_io_alloc(d->ctx, IN_FLOATS * sizeof(float), &d->d_in) != DP_OK || dp_io_alloc(d->ctx, OUT_FLOATS * sizeof(float), &d->d_out) != DP_OK ||
+    if (dp_io_alloc_host(d->ctx, IN_FLOATS * sizeof(float), (void**)&d->h_in) != DP_OK || dp_io_alloc_host(d->ctx, OUT_FLOATS * sizeof(float), (void**)&d->h_out) != DP_OK ||
+        dp_io_alloc(d->ctx, IN_FLOATS * sizeof(float), &d->d_in) != DP_OK || dp_io_alloc(d->ctx, OUT_FLOATS * sizeof(float), &d->d_out) != DP_OK ||
         dp_io_alloc(d->ctx, ST_FLOATS * sizeof(float), &d->d_state) != DP_OK) {
         d->fail(std::string("device buffers: ") + dp_last_error(d->ctx));
         return;
@@ -399,8 +403,8 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
         d->fail("drag_pose: maxIter must be in [1, " + std::to_string(DP_MAX_ITERS) + "]");
         return;
     }
-    float in[IN_FLOATS];
-    std::memset(in, 0, sizeof(in));
+    float* in = d->h_in;
+    std::memset(in, 0, IN_FLOATS * sizeof(float));
     std::memcpy(in + IN_Z0, d->latent, sizeof(d->latent)); // (the staged z_tgt stays 0: used when the pull term is off)
     in[IN_ROT] = d->cur_rot.w; in[IN_ROT + 1] = d->cur_rot.x; in[IN_ROT + 2] = d->cur_rot.y; in[IN_ROT + 3] = d->cur_rot.z;
     unsigned char* trk = (unsigned char*)(in + IN_TRK);
@@ -475,10 +479,10 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     dp_seq_step step;
     std::memset(&step, 0, sizeof(step));
     step.adjust_joint = -1; step.adjust_target_joint = -1;
-    float out[OUT_FLOATS];
-    if (dp_io_upload(d->ctx, di, in, sizeof(in), nullptr) != DP_OK ||
+    float* out = d->h_out;
+    if (dp_io_upload(d->ctx, di, in, IN_FLOATS * sizeof(float), nullptr) != DP_OK ||
         dp_optimize_sequence(d->ctx, 1, dout + OUT_Z, &fr, &p, &st, &step, &r, nullptr) != DP_OK ||
-        dp_io_download(d->ctx, out, dout, sizeof(out), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
+        dp_io_download(d->ctx, out, dout, OUT_FLOATS * sizeof(float), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
         d->fail(std::string("drag_pose: ") + dp_last_error(d->ctx));
         return;
     }
@@ -510,6 +514,7 @@ void destroy_drag_poser(DragPoser* d)
     if (!d) return;
     if (d->ctx) {
         for (void* p : {d->d_in, d->d_out, d->d_state, d->d_target}) if (p) dp_io_free(d->ctx, p);
+        for (float* p : {d->h_in, d->h_out}) if (p) dp_io_free_host(d->ctx, p);
         if (d->temporal) dp_temporal_destroy(d->temporal);
         dp_destroy(d->ctx);
     }

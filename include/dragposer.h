@@ -300,6 +300,11 @@ int dp_io_free(dp_ctx* ctx, void* dev_ptr);
 int dp_io_upload(dp_ctx* ctx, void* dev_dst, const void* host_src, unsigned long long bytes, void* hip_stream);
 int dp_io_download(dp_ctx* ctx, void* host_dst, const void* dev_src, unsigned long long bytes, void* hip_stream);
 int dp_stream_sync(dp_ctx* ctx, void* hip_stream);
+/* page-locked HOST staging memory for dp_io_upload / dp_io_download (hipHostMalloc / hipHostFree): a copy from or into pageable
+ * memory goes through the runtime's own staging buffer and blocks the caller; from pinned memory it is one asynchronous DMA.  New in
+ * 0.4.0; the native Unity drop-in stages every frame's inputs and results through such buffers. */
+int dp_io_alloc_host(dp_ctx* ctx, unsigned long long bytes, void** host_ptr);
+int dp_io_free_host(dp_ctx* ctx, void* host_ptr);
 
 /* introspection for the benchmark: frames per workgroup, workgroup size and LDS bytes of the kernel the context's
  * last dp_optimize / dp_forward launch used */

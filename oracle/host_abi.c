@@ -177,3 +177,5 @@ int dp_io_free(dp_ctx* c, void* p) { if (!c) return DP_ERR_INVALID; free(p); ret
 int dp_io_upload(dp_ctx* c, void* d, const void* s, unsigned long long n, void* q) { (void)q; if (!c || !d || !s) return DP_ERR_INVALID; memcpy(d, s, n); return DP_OK; }
 int dp_io_download(dp_ctx* c, void* d, const void* s, unsigned long long n, void* q) { (void)q; if (!c || !d || !s) return DP_ERR_INVALID; memcpy(d, s, n); return DP_OK; }
 int dp_stream_sync(dp_ctx* c, void* q) { (void)q; return c ? DP_OK : DP_ERR_INVALID; }
+int dp_io_alloc_host(dp_ctx* c, unsigned long long n, void** p) { if (!c || !p) return DP_ERR_INVALID; *p = calloc(1, n); return *p ? DP_OK : DP_ERR_DEVICE; }
+int dp_io_free_host(dp_ctx* c, void* p) { if (!c) return DP_ERR_INVALID; free(p); return DP_OK; }

@@ -49,4 +49,20 @@ for lam, window, label in ((0.0, 0, "pull term off"), (0.02, 0, "temporal term o
     assert lib.drag_poser_last_error(h) == b""
     print(f"drag_pose(), 6 trackers, maxIter 10, {label}: {dt * 1e6:.0f} us per call", flush=True)
 lib.destroy_drag_poser(h)
+# and without a predictor (no temporal.bin in the model folder): the optimise loop alone
+os.remove(os.path.join(tmp, "temporal.bin"))
+h = lib.init_drag_poser()
+lib.set_reference_skeleton(h, U.CLIP.encode())
+lib.load_models(h, tmp.encode())
+lib.set_mask_and_weights(h, mask.ctypes.data_as(C.POINTER(C.c_float)), w.ctypes.data_as(C.POINTER(U.F2)))
+lib.set_optim_params(h, 1e-4, 1e-2, 10, 1e-2)
+lib.set_lambdas(h, 1.0, 0.0, 0)
+lib.init_drag_model(h, U.F3(0.0, 0.0, 0.0), U.Qt(*[float(v) for v in b["cur_rot"][0]]))
+for k in range(32):
+    lib.drag_pose(h, 6, frames[k % 64][0], frames[k % 64][1], res_pose, res_pos)
+t0 = time.perf_counter()
+for k in range(320):
+    lib.drag_pose(h, 6, frames[k % 64][0], frames[k % 64][1], res_pose, res_pos)
+print(f"drag_pose(), 6 trackers, maxIter 10, no predictor loaded: {(time.perf_counter() - t0) / 320 * 1e6:.0f} us per call", flush=True)
+lib.destroy_drag_poser(h)
 shutil.rmtree(tmp)
