@@ -73,7 +73,12 @@ DEV Q4 q_from_rotmat(const float* m)
 }
 
 // ---------------------------------------------------------------- across lane groups (lanes f, f + 16, f + 32, f + 48 = one frame)
+// (W16_ABLATE_*: diagnostic builds that leave one part of the iteration out -- they compute nonsense, only their time is read: tools/ablate_w16.sh)
+#ifdef W16_ABLATE_BPERM
+DEV float bperm(int byte_addr, float v) { return v + __int_as_float(byte_addr & 1); }
+#else
 DEV float bperm(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+#endif
 DEV V3 bperm3(int a, V3 v) { return {bperm(a, v.x), bperm(a, v.y), bperm(a, v.z)}; }
 DEV Q4 bperm4(int a, Q4 q) { return {bperm(a, q.w), bperm(a, q.x), bperm(a, q.y), bperm(a, q.z)}; }
 DEV float sum_groups(float v)
@@ -91,6 +96,10 @@ DEV unsigned cvt_pk(float lo, float hi) { return __builtin_bit_cast(unsigned, __
 DEV void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l)
 { // x = h + m + l exactly (round-to-nearest bf16 at every stage; the remainders are exact fp32 differences)
     h = cvt_pk(x0, x1);
+#ifdef W16_ABLATE_SPLIT
+    m = h ^ 0x00010001u; l = h ^ 0x00020002u;
+    return;
+#endif
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
     m = cvt_pk(r0, r1);
     const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
@@ -133,6 +142,9 @@ DEV void pin_reads() { __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x
 // one pair: acc += W x, the six term products above 2^-24, small ones first
 DEV f4 pair_mm(f4 acc, const W3& w, const B3& b)
 {
+#ifdef W16_ABLATE_MM5
+    return mm(w.h, b.t[0], acc);
+#endif
     acc = mm(w.l, b.t[0], acc);
     acc = mm(w.m, b.t[1], acc);
     acc = mm(w.h, b.t[2], acc);
@@ -253,6 +265,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
             k8[t] = -8.f * (a.lam_rot * wr_raw[t] * invE * (1.f / 9.f));
         }
     }
+#ifdef W16_ABLATE_T
+    slotmask = 0;
+#endif
     const bool is_root = g == 0, is_pad3 = g == 3; // slot 4 of group 0 = root, slot 5 of group 0 = displacement, slot 5 of group 3 = idle
     const int src_f0 = 4 * f, src_g2 = 4 * (f + 32), src_prev = 4 * (lane >= 16 ? lane - 16 : lane), src_next = 4 * (lane < 48 ? lane + 16 : lane);
 
@@ -314,6 +329,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         y[2] = out_tile<L2, 2, pair_of(L2, 3), PREF>(img, wq, bias_row(lbias, 9, g), b1);
         y[3] = out_tile<L2, 3, pair_of(B2, 0), PREF>(img, wq, bias_row(lbias, 10, g), b1); // (bL2's first block rides through the kinematics)
 
+#ifdef W16_ABLATE_KIN
+        f4 gy[NTY];
+        bool was_act = true, stop_now = false;
+#pragma unroll
+        for (int t = 0; t < NTY; ++t) { gy[t] = y[t]; q[t] = {y[t].x, y[t].y, y[t].z, y[t].w}; P[t] = {y[t].x, y[t].y, y[t].z}; }
+#else
         // ================= stage J: normalise, bones, positions relative to the root
 #pragma unroll
         for (int t = 0; t < NTY; ++t) {
@@ -445,6 +466,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
             if (t == 5) gy[t] = is_root ? f4{GD.x, GD.y, GD.z, 0.f} : (is_pad3 ? f4{0.f, 0.f, 0.f, 0.f} : gy[t]);
         }
 
+#endif
         // ================= backward: d1 = (A2'^T gy) lrelu'(a1), d0 = (A1^T d1) lrelu'(a0), dL/dz = A0^T d0 + temporal term
         B3 by[3], bd1[2], bd0[2];
         by[0] = split_block(gy[0], gy[1]);
