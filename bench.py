@@ -245,7 +245,7 @@ def main():
     else:  # weak scaling: every rank its own batch of --frames
         batch = synth_on_device(opt, args.frames, 1234 + rank, device, mixed=s4)
         B, total_per_step = args.frames, args.frames * world
-    names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
+    names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters", "status", "clock")
     out = opt.optimize(**batch, n_iter=N, outputs=names, kernel=args.kernel)
     torch.cuda.synchronize()
 
@@ -268,6 +268,9 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     fpb, tpb, lds_bytes = opt.kernel_geometry()
+    from dragposer_amd.optimizer import sclk_ghz
+
+    sclk = sclk_ghz(out["clock"])  # the shader clock the LAST timed launch ran at (dp_result.clock: workgroup 0's cycles / 100 MHz ticks)
 
     # ---- parity on a sample (rank-local), reduced with the timing
     err_mm = float("nan")
@@ -319,6 +322,9 @@ def main():
                          "traffic_note": (traffic_note if traffic is not None else
                                           f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes ({PMC_FILE}, same command)")
                                          + f"; algorithmic {Bk * 2326:.3g}",
+                         # the roofline's 157.3 TF is the fp32 matrix rate AT 2.4 GHz; the chip holds less than that with every SIMD on the matrix pipe
+                         # (profiles/r05_clock_ramp.txt).  frac above stays against the full 157.3; this is the same work against the clock actually held
+                         "sclk_ghz": sclk, "frac_at_held_clock": achieved / (PEAK_F32_MFMA * sclk / 2.4) if sclk == sclk and sclk > 0 else None,
                          "kernel": {16: "dp_w4_kernel<4, false>", 64: "dp_w16_kernel<4, 1>", 128: "dp_w16_kernel<8, 2>"}.get(fpb, "?"), "kernel_ms": kern_ms,
                          "frac_of_bf16_mfma_peak_2.5PF": (achieved / 2.5e15 if fpb >= 64 else None),
                          "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},

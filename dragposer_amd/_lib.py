@@ -49,9 +49,17 @@ class DpBatch(C.Structure):
     ]
 
 
-class DpParams(C.Structure):
+class _Sized(C.Structure):
+    """dp_params / dp_result start with struct_size = sizeof the struct as THIS binding declares it (include/dragposer.h, 0.5.0)"""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(type(self))
+
+
+class DpParams(_Sized):
     _fields_ = [
-        ("n_iter", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("struct_size", C.c_uint), ("n_iter", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("lambda_rot", C.c_float), ("lambda_tmp", C.c_float), ("early_stop", C.c_int),
         ("stop_eps_pos", C.c_float), ("stop_eps_rot", C.c_float), ("min_loss_incr", C.c_float), ("max_trackers", C.c_int),
         ("kernel", C.c_int),
@@ -79,9 +87,10 @@ class DpSeqFrames(C.Structure):
     ]
 
 
-class DpSeqResults(C.Structure):
-    _fields_ = [("pose_ret", C.c_void_p), ("pos_ret", C.c_void_p), ("world_rot", C.c_void_p), ("iters", C.c_void_p), ("loss", C.c_void_p),
-                ("hist_scratch", C.c_void_p)]
+class DpSeqResults(_Sized):
+    _fields_ = [("struct_size", C.c_uint), ("reserved0", C.c_uint),
+                ("pose_ret", C.c_void_p), ("pos_ret", C.c_void_p), ("world_rot", C.c_void_p), ("iters", C.c_void_p), ("loss", C.c_void_p),
+                ("hist_scratch", C.c_void_p), ("status", C.c_void_p)]
 
 
 class DpTemporalLayer(C.Structure):
@@ -102,12 +111,16 @@ class DpTemporalModel(C.Structure):
     ]
 
 
-class DpResult(C.Structure):
+class DpResult(_Sized):
     _fields_ = [
-        ("z", C.c_void_p), ("z_pre", C.c_void_p), ("pose", C.c_void_p), ("disp", C.c_void_p),
+        ("struct_size", C.c_uint), ("reserved0", C.c_uint), ("z", C.c_void_p), ("z_pre", C.c_void_p), ("pose", C.c_void_p), ("disp", C.c_void_p),
         ("world_disp", C.c_void_p), ("world_rot", C.c_void_p), ("pos", C.c_void_p), ("rot", C.c_void_p),
-        ("loss", C.c_void_p), ("iters", C.c_void_p),
+        ("loss", C.c_void_p), ("iters", C.c_void_p), ("status", C.c_void_p), ("clock", C.c_void_p),
     ]
+
+
+DP_STATUS_NONFINITE_RESULT, DP_STATUS_BAD_STATE, DP_STATUS_BAD_TARGETS = 1, 2, 4
+DP_INPUT_LIMIT = 1.0e4
 
 
 # every symbol include/dragposer.h declares (checked by tests/test_abi.py)
@@ -154,6 +167,8 @@ def load(path=None):
     lib.dp_kernel_geometry.argtypes = [C.c_void_p, _i, _i, _i]
     lib.dp_auto_kernel.argtypes = [C.c_void_p, C.c_int]
     lib.dp_auto_kernel.restype = C.c_int
+    lib.dp_io_alloc_host.argtypes = [C.c_void_p, C.c_ulonglong, C.POINTER(C.c_void_p)]
+    lib.dp_io_free_host.argtypes = [C.c_void_p, C.c_void_p]
     lib.dp_temporal_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(DpTemporalModel), C.c_int]
     lib.dp_temporal_destroy.argtypes = [C.c_void_p]
     lib.dp_temporal_last_error.restype = C.c_char_p

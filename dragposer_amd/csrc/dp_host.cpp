@@ -2,7 +2,9 @@
 // skeleton tables, context management and the C ABI declared in include/dragposer.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -589,9 +591,36 @@ static void fill_model_args(const dp_ctx* ctx, KArgs& k)
     std::memcpy(k.smask, ctx->smask.data(), sizeof(k.smask));
 }
 
+// dp_params / dp_result as the caller compiled them (include/dragposer.h: struct_size): a copy of the first struct_size bytes over a zeroed
+// struct of THIS build -- a field the caller's header did not have reads as its default, a caller built against a pre-0.5 header is refused
+constexpr unsigned PARAMS_SIZE_V500 = offsetof(dp_params, kernel) + sizeof(int);
+constexpr unsigned RESULT_SIZE_V500 = offsetof(dp_result, clock) + sizeof(void*);
+static int take_params(dp_ctx* ctx, const dp_params* p, dp_params& o, const char* who)
+{
+    if (p->struct_size < PARAMS_SIZE_V500 || p->struct_size > 4096u)
+        return fail(ctx, DP_ERR_INVALID, std::string(who) + ": dp_params.struct_size is " + std::to_string(p->struct_size) + ", this library (DP_VERSION " +
+                                             std::to_string(DP_VERSION) + ") expects at least " + std::to_string(PARAMS_SIZE_V500) +
+                                             " -- was the caller compiled against a pre-0.5 dragposer.h?  (dp_params p = DP_PARAMS_INIT;)");
+    std::memset(&o, 0, sizeof(o));
+    std::memcpy(&o, p, std::min<size_t>(p->struct_size, sizeof(o)));
+    return DP_OK;
+}
+static int take_result(dp_ctx* ctx, const dp_result* r, dp_result& o, const char* who)
+{
+    std::memset(&o, 0, sizeof(o));
+    if (!r) return DP_OK;
+    if (r->struct_size < RESULT_SIZE_V500 || r->struct_size > 4096u || r->reserved0 != 0u)
+        return fail(ctx, DP_ERR_INVALID, std::string(who) + ": dp_result.struct_size is " + std::to_string(r->struct_size) + " (reserved0 " +
+                                             std::to_string(r->reserved0) + "), this library (DP_VERSION " + std::to_string(DP_VERSION) + ") expects at least " +
+                                             std::to_string(RESULT_SIZE_V500) + " and reserved0 = 0 -- was the caller compiled against a pre-0.5 dragposer.h?  (dp_result r = DP_RESULT_INIT;)");
+    std::memcpy(&o, r, std::min<size_t>(r->struct_size, sizeof(o)));
+    return DP_OK;
+}
+
 static void fill_results(const dp_result* out, KArgs& k)
 {
     if (!out) return;
+    k.status = out->status; k.clk = out->clock;
     k.z = out->z; k.z_pre = out->z_pre; k.pose = out->pose; k.disp = out->disp; k.world_disp = out->world_disp;
     k.world_rot = out->world_rot; k.pos = out->pos; k.rot = out->rot; k.loss = out->loss; k.iters = out->iters;
 }
@@ -619,10 +648,15 @@ static int launch(dp_ctx* ctx, KArgs& k, void* stream, int kernel = DP_KERNEL_W4
 
 // private extension used by the tests: same as dp_optimize, plus an optional debug dump
 // [B][240] = y(104) | dL/dy(104) | dL/dz(24) | pad, all of iteration 0.
-extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_result* out, float* dbg, void* stream)
+extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_params* p_in, const dp_result* out_in, float* dbg, void* stream)
 {
     if (!ctx) return DP_ERR_INVALID;
-    if (!in || !p) return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL batch/params");
+    if (!in || !p_in) return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL batch/params");
+    dp_params pv; dp_result ov;
+    if (int rc = take_params(ctx, p_in, pv, "dp_optimize")) return rc;
+    if (int rc = take_result(ctx, out_in, ov, "dp_optimize")) return rc;
+    const dp_params* p = &pv;
+    const dp_result* out = &ov;
     if (in->n_frames <= 0) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_frames must be positive");
     if (!in->z0 || !in->z_tgt || !in->cur_rot || !in->tgt_pos || !in->tgt_rot || !in->w || !in->tracked)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL input array");
@@ -680,25 +714,42 @@ extern "C" int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float
 {
     if (!ctx) return DP_ERR_INVALID;
     if (n_frames <= 0 || !z || !cur_rot || !out) return fail(ctx, DP_ERR_INVALID, "dp_forward: bad arguments");
+    dp_result ov;
+    if (int rc = take_result(ctx, out, ov, "dp_forward")) return rc;
+    out = &ov;
     KArgs k;
     fill_model_args(ctx, k);
     k.z0 = z; k.cur_rot = cur_rot;
     fill_results(out, k);
-    k.z = nullptr; k.z_pre = nullptr; k.loss = nullptr; k.iters = nullptr;
+    k.z = nullptr; k.z_pre = nullptr; k.loss = nullptr; k.iters = nullptr; k.clk = nullptr;
     k.n_frames = n_frames; k.n_iter = 1; k.mode = 1;
     return launch(ctx, k, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
 // n_steps frames of S sequences in one launch (+ one for the history buffers), see include/dragposer.h
-extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const dp_seq_frames* fr, const dp_params* p, const dp_seq_state* st,
+extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const dp_seq_frames* fr, const dp_params* p_in, const dp_seq_state* st,
                                     const dp_seq_step* adj, const dp_seq_results* out, void* stream)
 {
     if (!ctx) return DP_ERR_INVALID;
 #ifdef DP_REF8_BUILD
     return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize_sequence: not part of the test-only library");
 #else
-    if (n_seq <= 0 || !latent || !fr || !p || !st || !out) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad arguments");
+    if (n_seq <= 0 || !latent || !fr || !p_in || !st || !out) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad arguments");
+    dp_params pv;
+    if (int rc = take_params(ctx, p_in, pv, "dp_optimize_sequence")) return rc;
+    const dp_params* p = &pv;
+    dp_seq_results ov;
+    {
+        constexpr unsigned SEQ_RESULTS_SIZE_V500 = offsetof(dp_seq_results, status) + sizeof(void*);
+        if (out->struct_size < SEQ_RESULTS_SIZE_V500 || out->struct_size > 4096u || out->reserved0 != 0u)
+            return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: dp_seq_results.struct_size is " + std::to_string(out->struct_size) + ", this library (DP_VERSION " +
+                                                 std::to_string(DP_VERSION) + ") expects at least " + std::to_string(SEQ_RESULTS_SIZE_V500) +
+                                                 " and reserved0 = 0 -- was the caller compiled against a pre-0.5 dragposer.h?  (dp_seq_results r = DP_SEQ_RESULTS_INIT;)");
+        std::memset(&ov, 0, sizeof(ov));
+        std::memcpy(&ov, out, std::min<size_t>(out->struct_size, sizeof(ov)));
+        out = &ov;
+    }
     if (fr->n_steps <= 0 || !fr->tgt_pos || !fr->tgt_rot || !fr->w || !fr->tracked || !fr->z_tgt)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: NULL input array / n_steps must be positive");
     if (!st->global_pos || !st->global_rot || !st->latent_buf || !st->disp_buf || !st->heights_buf || !out->hist_scratch)
@@ -716,7 +767,7 @@ extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const
     KArgs k;
     fill_model_args(ctx, k);
     k.z0 = latent; k.z_tgt = fr->z_tgt; k.cur_rot = st->global_rot; k.tgt_pos = fr->tgt_pos; k.tgt_rot = fr->tgt_rot; k.w = fr->w; k.tracked = fr->tracked;
-    k.z = latent; k.pose = out->pose_ret; k.world_rot = out->world_rot; k.iters = out->iters; k.loss = out->loss;
+    k.z = latent; k.pose = out->pose_ret; k.world_rot = out->world_rot; k.iters = out->iters; k.loss = out->loss; k.status = out->status;
     k.n_frames = n_seq; k.n_iter = p->n_iter; k.mode = 0;
     k.lam_rot = p->lambda_rot; k.lam_tmp = p->lambda_tmp; k.ctmp = 2.f * p->lambda_tmp / 24.f;
     k.beta2 = p->beta2; k.one_m_b1 = (float)(1.0 - (double)p->beta1); k.one_m_b2 = (float)(1.0 - (double)p->beta2);
@@ -757,6 +808,9 @@ extern "C" int dp_sequence_advance(dp_ctx* ctx, int n_seq, const dp_result* res,
 {
     if (!ctx) return DP_ERR_INVALID;
     if (n_seq <= 0 || !res || !st || !step) return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: bad arguments");
+    dp_result rv;
+    if (int rc = take_result(ctx, res, rv, "dp_sequence_advance")) return rc;
+    res = &rv;
     if (!res->z_pre || !res->pose || !res->disp || !res->world_disp || !res->world_rot || !res->pos)
         return fail(ctx, DP_ERR_INVALID, "dp_sequence_advance: the frame result needs z_pre, pose, disp, world_disp, world_rot and pos");
     if (!st->global_pos || !st->global_rot || !st->latent_buf || !st->disp_buf || !st->heights_buf)

@@ -48,6 +48,8 @@ struct KArgs {
     // results (device, nullable)
     float *z, *z_pre, *pose, *disp, *world_disp, *world_rot, *pos, *rot, *loss;
     int* iters;
+    int* status;             // [B] DP_STATUS_* bits, nullable
+    unsigned long long* clk; // [2] shader cycles / 100 MHz ticks of workgroup 0's iteration loop, nullable
     float* dbg;
     int n_frames, n_iter, mode; // mode 0: optimise, 1: forward only (n_iter = 1)
     int early_stop;             // per-frame while-condition of drag_pose.py:300-304

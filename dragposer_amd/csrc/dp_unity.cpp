@@ -455,7 +455,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
         if (d->current_index > d->window) { d->fail("drag_pose: temporal window index out of range"); return; } // (cannot happen: see above)
         b.z_tgt = (float*)d->d_target + (size_t)d->current_index * LAT;
     }
-    dp_params p;
+    dp_params p = DP_PARAMS_INIT;
     p.n_iter = d->max_iter; p.lr = d->lr; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f;
     p.lambda_rot = d->lambda_rot; p.lambda_tmp = pull ? d->lambda_tmp : 0.f;
     p.early_stop = 1; p.stop_eps_pos = d->stop_eps_pos; p.stop_eps_rot = d->stop_eps_rot; p.min_loss_incr = 0.00001f; // run() default
@@ -471,8 +471,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     fr.z_tgt = b.z_tgt; fr.z_tgt_step = 0; fr.z_tgt_seq = LAT;
     // everything the host needs back lands in ONE device block (one download per frame): the latent (device-resident, in/out),
     // the returned pose, the global position and rotation after the step, the iteration count
-    dp_seq_results r;
-    std::memset(&r, 0, sizeof(r));
+    dp_seq_results r = DP_SEQ_RESULTS_INIT;
     r.pose_ret = dout + OUT_POSE; r.pos_ret = dout + OUT_WD; r.world_rot = dout + OUT_WR; r.iters = (int*)(dout + OUT_ITERS); r.loss = dout + OUT_LOSS;
     r.hist_scratch = dout + OUT_POS; // (LAT + 3 + NHGT floats of scratch: the block's joint-position area is unused on this path)
     static_assert(NJ * 3 >= LAT + 3 + NHGT, "the history scratch row fits");
@@ -483,7 +482,10 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     if (dp_io_upload(d->ctx, di, in, IN_FLOATS * sizeof(float), nullptr) != DP_OK ||
         dp_optimize_sequence(d->ctx, 1, dout + OUT_Z, &fr, &p, &st, &step, &r, nullptr) != DP_OK ||
         dp_io_download(d->ctx, out, dout, OUT_FLOATS * sizeof(float), nullptr) != DP_OK || dp_stream_sync(d->ctx, nullptr) != DP_OK) {
-        d->fail(std::string("drag_pose: ") + dp_last_error(d->ctx));
+        const std::string why = dp_last_error(d->ctx);
+        dp_stream_sync(d->ctx, nullptr); // h_in / h_out are page-locked: an upload or download queued before the failure is an asynchronous DMA, and
+                                         // the next drag_pose() rewrites h_in -- nothing may still be in flight when this one returns
+        d->fail("drag_pose: " + why);
         return;
     }
     // the state the kernel left (drag_pose.py:369-371), mirrored on the host

@@ -33,7 +33,9 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 constexpr int L16_IMG = 0;
 constexpr int L16_BIAS = L16_IMG + IMG_U32;
 constexpr int L16_TAB = L16_BIAS + BIAS_FLOATS; // per-iteration Adam scalars [MAX_ITERS][2]
-constexpr int L16_END = L16_TAB + 2 * MAX_ITERS;
+constexpr int L16_FLAGS = L16_TAB + 2 * MAX_ITERS; // [8 waves][16 frames] DP_STATUS_BAD_* of the input screening, parked for the epilogue
+constexpr int L16_CLK = L16_FLAGS + 8 * FPW;       // [4] the two start stamps of dp_result.clock (64 bits each)
+constexpr int L16_END = L16_CLK + 4;
 
 // ---------------------------------------------------------------- small vector helpers
 DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -224,6 +226,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     }
     const f4 cv = *(const f4*)(a.cur_rot + (size_t)gf * 4);
     const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
+    // input screening (include/dragposer.h: DP_STATUS_*; dp_w4.hip has the long story).  A frame is a lane column here and nothing crosses
+    // columns, so a frame with a non-finite input needs no stand-in values: it is handed over AS non-finite -- the state (z) or the pull
+    // target (z_tgt) set to NaN -- and the arithmetic then does what the reference's does (NaN loss on the first pass, the while-condition
+    // fails, Adam writes NaN into the latent).  Inputs beyond DP_INPUT_LIMIT are treated the same way, as dp_w4 treats them.
+    const auto oor = [](float x) { return !(fabsf(x) <= DP_INPUT_LIMIT); };
+    float bad_s = (oor(cv.x) || oor(cv.y) || oor(cv.z) || oor(cv.w)) ? 1.f : 0.f, bad_t = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bad_s += oor(z[n][r]) ? 1.f : 0.f; bad_t += oor(zt[n][r]) ? 1.f : 0.f; }
 
     // my six slots: constants and tracker inputs (targets rotated into the frame of cur_rot once; rotation targets as unit
     // quaternions; loss coefficients with the per-frame mean denominators 3 E, 9 E folded in)
@@ -249,6 +261,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         float m9[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) m9[k] = rm[k];
+        {
+            bool bd = oor(p[0]) || oor(p[1]) || oor(p[2]) || oor(wv[0]) || oor(wv[1]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) bd = bd || oor(m9[k]);
+            bad_t += trk && bd ? 1.f : 0.f;
+        }
         tp[t] = sel3(trk, rot_qc(cur, V3{p[0], p[1], p[2]}), V3{0.f, 0.f, 0.f});
         qT[t] = sel4(trk, quat_mul(qconj(cur), q_from_rotmat(m9)), Q4{1.f, 0.f, 0.f, 0.f});
         wp_raw[t] = trk ? wv[0] : 0.f;
@@ -265,6 +283,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
             k8[t] = -8.f * (a.lam_rot * wr_raw[t] * invE * (1.f / 9.f));
         }
     }
+    // (the two flags go to LDS for the epilogue: held in registers across the loop they cost the one-wave unit two spills)
+    {
+        const bool state_bad = sum_groups(bad_s) > 0.f, tgt_bad = !state_bad && sum_groups(bad_t) > 0.f; // (the same in the frame's four lanes)
+        if (g == 0) lds[L16_FLAGS + wave * FPW + f] = (state_bad ? DP_STATUS_BAD_STATE : 0) + (tgt_bad ? DP_STATUS_BAD_TARGETS : 0);
+    if (__ballot(state_bad || tgt_bad) != 0ull) { // (uniform, rare)
+        const float qnan = __builtin_nanf("");
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * n + 4 * g + r < LAT) { // (dims 24..31 stay zero)
+                    z[n][r] = state_bad ? qnan : z[n][r];
+                    zt[n][r] = tgt_bad ? qnan : zt[n][r];
+                }
+            }
+    }
+    }
 #ifdef W16_ABLATE_T
     slotmask = 0;
 #endif
@@ -273,6 +308,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 
     __syncthreads();
     if (f0 >= nB) return; // (uniform per wave; no barrier below)
+    // dp_result.clock: shader cycles and 100 MHz ticks wave 0 of workgroup 0 spends from here to its last store
+    // (the start stamps wait in LDS: four more scalar registers held across the loop cost this kernel spills)
+    if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) { // (uniform)
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) { *(unsigned long long*)(lds + L16_CLK) = c0; *(unsigned long long*)(lds + L16_CLK + 2) = r0; }
+    }
     // (Two waves per SIMD run the same program from the same barrier; a start delay for the second half of the workgroup -- so that one
     //  wave's matrix phases fall on the other's vector phases -- was measured and changes nothing: profiles/r03_w16_stagger.txt.)
     const float* lbias = (const float*)lds + L16_BIAS;
@@ -529,6 +570,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 #pragma unroll
         for (int n = 0; n < 2; ++n) { const f4 dz = zpre[n] - zt[n]; lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w; }
         lt = sum_groups(lt) * a.lam_tmp * (1.f / 24.f);
+    }
+    const int bad_flags = (int)lds[L16_FLAGS + wave * FPW + f]; // (written by this wave's own lanes before the set-up's barrier)
+    if (bad_flags != 0) lsum_p = lsum_r = lt = __builtin_nanf(""); // (the reference's total loss is NaN there; which of its terms are depends on the input)
+    if (a.status) { // (uniform)
+        float nf = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nf += !(fabsf(EARLY ? zfin[n][r] : z[n][r]) <= 3.0e38f) ? 1.f : 0.f;
+        nf = sum_groups(nf);
+        if (fvalid && g == 0)
+            a.status[gf] = (nf > 0.f ? DP_STATUS_NONFINITE_RESULT : 0) + bad_flags;
+    }
+    if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) { // (uniform; the result stores that follow are a percent of the launch and change the ratio of the two counters by nothing)
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[0] = c1 - *(const unsigned long long*)(lds + L16_CLK); a.clk[1] = r1 - *(const unsigned long long*)(lds + L16_CLK + 2); }
     }
     if (!fvalid) return;
     const Q4 qw = quat_mul(cur, q0); // world rotation (drag_pose.py:88)

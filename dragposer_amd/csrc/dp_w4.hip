@@ -329,7 +329,7 @@ struct StepArgs {
     const float* w4img;
     const float *z_tgt, *tgt_pos, *tgt_rot, *w;
     float *z, *z_pre, *pose, *disp, *world_disp, *world_rot, *pos, *rot, *loss;
-    int* iters;
+    int *iters, *status;
     int n_iter;
     float lam_rot, lam_tmp;
     SeqK seq;
@@ -342,7 +342,7 @@ DEV void stage_step_args(float* lds, const KArgs& a)
     d->z_tgt = a.z_tgt; d->tgt_pos = a.tgt_pos; d->tgt_rot = a.tgt_rot; d->w = a.w;
     d->z = a.z; d->z_pre = a.z_pre; d->pose = a.pose; d->disp = a.disp; d->world_disp = a.world_disp; d->world_rot = a.world_rot;
     d->pos = a.pos; d->rot = a.rot; d->loss = a.loss;
-    d->iters = a.iters;
+    d->iters = a.iters; d->status = a.status;
     d->n_iter = a.n_iter;
     d->lam_rot = a.lam_rot; d->lam_tmp = a.lam_tmp;
     d->seq = a.seq;
@@ -433,9 +433,38 @@ template <class A> DEV TRec tracker_finish(const A& a, float* fb, const TRaw& r,
     }
     return t;
 }
-template <class A> DEV TRec make_tracker(const A& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur, int gf_tgt = -1, V3 shift = V3{0.f, 0.f, 0.f})
+// ---- input screening (include/dragposer.h: DP_STATUS_*).  The four frames of a wave meet in the D <-> X transposes, which are matrix products
+// with unit rows: a NaN or Inf in one frame times the 0 of another frame's row is NaN -- one tracker drop-out would take the three neighbouring
+// frames (three other sequences, in a whole-sequence launch) with it.  The reference has no such coupling (it runs one frame at a time), so the
+// kernel screens its inputs once per launch (per step): a frame with a non-finite or absurd (> DP_INPUT_LIMIT) input is computed on neutral
+// values -- weights 0, z_tgt = z, so that its gradient is exactly zero and nothing in it ever leaves the finite range -- and its RESULTS are set
+// to what the reference returns for it (NaN; drag_pose.py:300-304,342-344), with the reason in dp_result.status.
+DEV bool out_of_range(float x) { return !(fabsf(x) <= DP_INPUT_LIMIT); } // NaN, Inf, or beyond the limit
+DEV bool raw_bad(const TRaw& r)
 {
-    return tracker_finish(a, fb, tracker_fetch(a, true, gf, tmask, E, rank, gf_tgt), E, cur, shift);
+    bool bad = out_of_range(r.p[0]) || out_of_range(r.p[1]) || out_of_range(r.p[2]) || out_of_range(r.wp) || out_of_range(r.wr);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) bad = bad || out_of_range(r.m[k]);
+    return r.act && bad;
+}
+DEV void raw_neutral(TRaw& r)
+{
+    r.p[0] = r.p[1] = r.p[2] = 0.f;
+    r.wp = r.wr = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+}
+DEV unsigned frames_of(unsigned long long votes)
+{ // bit i: some lane with (lane & 3) == i voted -- the lanes of frame i
+    votes |= votes >> 32; votes |= votes >> 16; votes |= votes >> 8; votes |= votes >> 4;
+    return (unsigned)votes & 0xFu;
+}
+DEV float poisoned(bool p, float v) { return p ? __builtin_nanf("") : v; }
+template <class A> DEV TRec make_tracker(const A& a, float* fb, int gf, unsigned tmask, int E, int rank, Q4 cur, int gf_tgt = -1, V3 shift = V3{0.f, 0.f, 0.f}, bool neutral = false)
+{
+    TRaw r = tracker_fetch(a, true, gf, tmask, E, rank, gf_tgt);
+    if (neutral) raw_neutral(r);
+    return tracker_finish(a, fb, r, E, cur, shift);
 }
 
 DEV TRec load_tracker(const KArgs& a, const float* fb, int E, int rank)
@@ -637,10 +666,11 @@ DEV void out_consts(const float* oc, int itemA, int kindA, int itemB, int kindB,
     oB.plo = __float_as_uint(pw.z); oB.phi = __float_as_uint(pw.w);
 }
 template <bool SEQ = false, class A>
-DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early)
-{ // SEQ (whole-sequence launches): gf = step * S + sequence; the state update's inputs are also left in the frame block, and the
+DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise, Q4 cur, unsigned tmask, bool early, bool pall = false, bool ploss = false)
+{ // pall / ploss: this frame failed the input screening -- every result / the loss is NaN (what stays in the frame block for the state update is not) // SEQ (whole-sequence launches): gf = step * S + sequence; the state update's inputs are also left in the frame block, and the
   // pose written is the one run() RETURNS (root channels = the normalised world rotation, drag_pose.py:394-396)
     const int item = oc.item, kind = oc.kind;
+    const auto P = [pall](float v) { return poisoned(pall, v); };
     if (item < 0 || kind == KIND_IDLE || kind == KIND_VIRT) return;
     const f4 sd = oc.sd, mu = oc.mu;
     const f4 qv = *(const f4*)(fb + FB_QS + 4 * item); // what stage J of the last forward pass left: unit quaternion / displacement
@@ -649,10 +679,10 @@ DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise
     const Q4 qw = quat_mul(cur, Q4{q0v.x, q0v.y, q0v.z, q0v.w}); // world rotation (drag_pose.py:88)
     const M3 R0 = quat_to_mat(qw);
     if (kind == KIND_DISP) {
-        if (a.disp) { gfloat* o = GM(a.disp) + (size_t)gf * 3; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; }
+        if (a.disp) { gfloat* o = GM(a.disp) + (size_t)gf * 3; o[0] = P(rq.w); o[1] = P(rq.x); o[2] = P(rq.y); }
         if (a.world_disp || SEQ) {
             const V3 wd = mat_vec(R0, V3{rq.w, rq.x, rq.y});
-            if (a.world_disp) { gfloat* o = GM(a.world_disp) + (size_t)gf * 3; o[0] = wd.x; o[1] = wd.y; o[2] = wd.z; }
+            if (a.world_disp) { gfloat* o = GM(a.world_disp) + (size_t)gf * 3; o[0] = P(wd.x); o[1] = P(wd.y); o[2] = P(wd.z); }
             if (SEQ) { *(f4*)(fb + FB_SWD) = f4{wd.x, wd.y, wd.z, 0.f}; *(f4*)(fb + FB_SD) = f4{rq.w, rq.x, rq.y, 0.f}; }
         }
         return;
@@ -661,10 +691,10 @@ DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise
     if (a.pose) {
         gfloat* o = GM(a.pose) + (size_t)gf * 88 + 4 * item;
         if (SEQ && kind == KIND_ROOT) {
-            o[0] = (qw.w - a.seq.mean_q0[0]) / a.seq.std_q0[0]; o[1] = (qw.x - a.seq.mean_q0[1]) / a.seq.std_q0[1];
-            o[2] = (qw.y - a.seq.mean_q0[2]) / a.seq.std_q0[2]; o[3] = (qw.z - a.seq.mean_q0[3]) / a.seq.std_q0[3];
+            o[0] = P((qw.w - a.seq.mean_q0[0]) / a.seq.std_q0[0]); o[1] = P((qw.x - a.seq.mean_q0[1]) / a.seq.std_q0[1]);
+            o[2] = P((qw.y - a.seq.mean_q0[2]) / a.seq.std_q0[2]); o[3] = P((qw.z - a.seq.mean_q0[3]) / a.seq.std_q0[3]);
         } else {
-            o[0] = (q.w - mu.x) / sd.x; o[1] = (q.x - mu.y) / sd.y; o[2] = (q.y - mu.z) / sd.z; o[3] = (q.z - mu.w) / sd.w;
+            o[0] = P((q.w - mu.x) / sd.x); o[1] = P((q.x - mu.y) / sd.y); o[2] = P((q.y - mu.z) / sd.z); o[3] = P((q.z - mu.w) / sd.w);
         }
     }
     if (a.pos || SEQ) {
@@ -677,7 +707,7 @@ DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise
 #pragma unroll
         for (int k = 0; k < MAX_PATH; ++k) { pr.x += bn[k].x; pr.y += bn[k].y; pr.z += bn[k].z; }
         const V3 pw = mat_vec(R0, pr);
-        if (a.pos) { gfloat* o = GM(a.pos) + ((size_t)gf * NJ + item) * 3; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
+        if (a.pos) { gfloat* o = GM(a.pos) + ((size_t)gf * NJ + item) * 3; o[0] = P(pw.x); o[1] = P(pw.y); o[2] = P(pw.z); }
         if (SEQ) { float* o = fb + FB_SPOS + 3 * item; o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; }
     }
     if (a.rot) {
@@ -685,15 +715,15 @@ DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise
         if (kind == KIND_ROOT) M = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
         const M3 G = mat_mat(R0, M);
         gfloat* o = GM(a.rot) + ((size_t)gf * NJ + item) * 9;
-        o[0] = G.m00; o[1] = G.m01; o[2] = G.m02; o[3] = G.m10; o[4] = G.m11; o[5] = G.m12; o[6] = G.m20; o[7] = G.m21; o[8] = G.m22;
+        o[0] = P(G.m00); o[1] = P(G.m01); o[2] = P(G.m02); o[3] = P(G.m10); o[4] = P(G.m11); o[5] = P(G.m12); o[6] = P(G.m20); o[7] = P(G.m21); o[8] = P(G.m22);
     }
     if (kind == KIND_ROOT) {
-        if (a.world_rot) { gfloat* o = GM(a.world_rot) + (size_t)gf * 4; o[0] = qw.w; o[1] = qw.x; o[2] = qw.y; o[3] = qw.z; }
+        if (a.world_rot) { gfloat* o = GM(a.world_rot) + (size_t)gf * 4; o[0] = P(qw.w); o[1] = P(qw.x); o[2] = P(qw.y); o[3] = P(qw.z); }
         if (SEQ) *(f4*)(fb + FB_SQW) = f4{qw.w, qw.x, qw.y, qw.z};
         if (optimise && a.loss && early) { // losses of the frame's last executed iteration, as the stop test saw them
             const f4 es = *(const f4*)(fb + FB_ES);
             gfloat* o = GM(a.loss) + (size_t)gf * 3;
-            o[0] = es.x; o[1] = es.y; o[2] = es.z;
+            o[0] = poisoned(ploss, es.x); o[1] = poisoned(ploss, es.y); o[2] = poisoned(ploss, es.z);
         } else if (optimise && a.loss) {
             float lsum_p = 0.f, lsum_r = 0.f, lt = 0.f;
             const int E = min(__popc(tmask), W4_R);
@@ -703,9 +733,9 @@ DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise
                 lt += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
             }
             gfloat* o = GM(a.loss) + (size_t)gf * 3;
-            o[0] = lsum_p;
-            o[1] = lsum_r;
-            o[2] = lt * a.lam_tmp * (1.f / 24.f);
+            o[0] = poisoned(ploss, lsum_p);
+            o[1] = poisoned(ploss, lsum_r);
+            o[2] = poisoned(ploss, lt * a.lam_tmp * (1.f / 24.f));
         }
     }
 }
@@ -782,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #pragma unroll
     for (int k = 0; k < 5; ++k) tflag[k] = ((const u32_any*)trow)[k];
     tflag[5] = *(const u16_any*)(trow + 20);
-    const f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
+    f4 cv = *(const f4*)(a.cur_rot + (size_t)gfi * 4);
     // per-lane accumulator seeds (bias rows of L0, L1, L2A, L2B)
     const float bias0 = a.w4bias[lane], bias1 = a.w4bias[64 + lane], bias2a = a.w4bias[128 + lane], bias2b = a.w4bias[192 + lane];
     // latent and Adam state in the D layout of the last product: lane = latent dim, register r = frame f0 + r
@@ -863,7 +893,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const int E = min(__popc(tmask), W4_R);
     const int Emax = max(max(__builtin_amdgcn_readlane(E, 0), __builtin_amdgcn_readlane(E, 1)),
                          max(__builtin_amdgcn_readlane(E, 2), __builtin_amdgcn_readlane(E, 3)));
-    const TRaw raw = tracker_fetch(a, optimise, gfi, tmask, E, b);
+    TRaw raw = tracker_fetch(a, optimise, gfi, tmask, E, b);
     SETUP_STAMP(0);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -895,6 +925,31 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         for (int k = 0; k < 5; ++k) *(f4*)(lds + L_OC + 20 * b + 4 * k) = ocv[k];
     }
     if (SEQ && tid == 0) stage_step_args(lds, a);
+    // ---- input screening (out_of_range above): which of my wave's four frames cannot be optimised, and their neutral stand-ins
+    unsigned bad_state = 0u, bad_tgt = 0u; // bit r: frame f0 + r (uniform per wave).  state: z0 / cur_rot; tgt: targets, weights, z_tgt
+    {
+        bool tb = !SEQ && raw_bad(raw); // (SEQ: every step screens its own targets, in the step loop)
+        if (!SEQ)
+            for (int base = 16; base < Emax; base += 16) tb = tb || raw_bad(tracker_fetch(a, true, gfi, tmask, E, base + b)); // (uniform, rare)
+        const bool cb = out_of_range(cv.x) || out_of_range(cv.y) || out_of_range(cv.z) || out_of_range(cv.w);
+        bad_tgt = frames_of(__ballot(tb));
+        bad_state = frames_of(__ballot(cb));
+#pragma unroll
+        for (int r = 0; r < FPW; ++r) {
+            bad_state |= (__ballot(lane < LAT && out_of_range(zD[r])) != 0ull ? 1u : 0u) << r;
+            if (!SEQ) bad_tgt |= (__ballot(lane < LAT && out_of_range(ztD[r])) != 0ull ? 1u : 0u) << r;
+        }
+        bad_tgt &= ~bad_state;
+        if (bad_state | bad_tgt) { // (uniform, rare)
+            if (((bad_state | bad_tgt) >> i) & 1u) raw_neutral(raw);
+            if ((bad_state >> i) & 1u) cv = f4{1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < FPW; ++r) {
+                if ((bad_state >> r) & 1u) zD[r] = 0.f;
+                if (((bad_state | bad_tgt) >> r) & 1u) ztD[r] = zD[r]; // no pull: with the weights at zero the frame's gradient is exactly zero
+            }
+        }
+    }
     if (b == 0) *(f4*)(fb + FB_CUR) = cv;
     wave_sync(); // (the zero fill above and the tracker records below touch the same frame blocks from different lanes)
 
@@ -928,7 +983,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         //  sequence cut into launches of any lengths gives the same bits)
         if (!SEQ) {
             trk = tracker_finish(a, fb, raw, E, cur, shift);
-            for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur, -1, shift); // (uniform, rare)
+            for (int base = 16; base < Emax; base += 16) make_tracker(a, fb, gfi, tmask, E, base + b, cur, -1, shift, ((bad_state | bad_tgt) >> i) & 1u); // (uniform, rare)
         } else {
             trk = TRec{};
         }
@@ -965,6 +1020,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.t[15] = prof.prev - t_setup[2];  // resident weights arrived
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;
 #endif
+    // dp_result.clock: shader cycles and 100 MHz ticks workgroup 0 spends from here to its last store (four scalar instructions per launch)
+    const bool clk_on = a.clk != nullptr && blockIdx.x == 0 && wave == 0; // (uniform)
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_on) { clk_r0 = __builtin_amdgcn_s_memrealtime(); clk_c0 = __builtin_amdgcn_s_memtime(); }
     int step = 0;
 #ifdef DP_SEQ_STAMPS // diagnostic build (tools/seq_step_stamps.sh): where a step of a whole-sequence launch spends its cycles
     unsigned long long sq_t[5] = {0, 0, 0, 0, 0}, sq_p = __builtin_amdgcn_s_memtime();
@@ -984,22 +1043,49 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             step_shift = {rp[0] - gpv.x, rp[1] - gpv.y, rp[2] - gpv.z};
         }
         { // this frame of every sequence: its targets, a warm-started latent, a fresh Adam state (drag_pose.py:218)
-            const f4 cvs = *(const f4*)(fb + FB_CUR);
-            const Q4 cur = {cvs.x, cvs.y, cvs.z, cvs.w};
-            trk = tracker_finish(as, fb, tracker_fetch(as, true, gfi, tmask, E, b, gft), E, cur, step_shift);
-            for (int base = 16; base < Emax; base += 16) make_tracker(as, fb, gfi, tmask, E, base + b, cur, gft, step_shift); // (uniform, rare)
+            f4 cvs = *(const f4*)(fb + FB_CUR);
+            TRaw rs = tracker_fetch(as, true, gfi, tmask, E, b, gft);
             if (step > 0) zD = zfinD;
-            zfinD = zD;
             mD = f4{0.f, 0.f, 0.f, 0.f}; vD = mD;
             if (lane < LAT) {
 #pragma unroll
                 for (int r = 0; r < FPW; ++r) {
                     const int gf = min(f0 + r, nB - 1);
                     ztD[r] = GM(as.z_tgt)[(size_t)step * as.seq.z_tgt_step + (size_t)gf * as.seq.z_tgt_seq + lane];
-                    const float dz = zD[r] - ztD[r];
-                    fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz;
                 }
             }
+            // input screening of this step: a sequence whose previous step could not be optimised has a NaN latent in the reference from then
+            // on (drag_pose.py:342-344 wrote it): sticky
+            bad_state |= bad_tgt;
+            {
+                bool tb = raw_bad(rs) || out_of_range(step_shift.x) || out_of_range(step_shift.y) || out_of_range(step_shift.z);
+                for (int base = 16; base < Emax; base += 16) tb = tb || raw_bad(tracker_fetch(as, true, gfi, tmask, E, base + b, gft)); // (uniform, rare)
+                bad_tgt = frames_of(__ballot(tb));
+#pragma unroll
+                for (int r = 0; r < FPW; ++r) bad_tgt |= (__ballot(lane < LAT && out_of_range(ztD[r])) != 0ull ? 1u : 0u) << r;
+                bad_tgt &= ~bad_state;
+            }
+            const bool my_bad = ((bad_state | bad_tgt) >> i) & 1u;
+            if (bad_state | bad_tgt) { // (uniform, rare) neutral stand-ins: the frame's state stays finite, its results are poisoned in the epilogue
+                if (my_bad) { raw_neutral(rs); step_shift = V3{0.f, 0.f, 0.f}; }
+                if ((bad_state >> i) & 1u) {
+                    cvs = f4{1.f, 0.f, 0.f, 0.f};
+                    if (b == 0) *(f4*)(fb + FB_CUR) = cvs;
+                }
+#pragma unroll
+                for (int r = 0; r < FPW; ++r) {
+                    if ((bad_state >> r) & 1u) zD[r] = 0.f;
+                    if (((bad_state | bad_tgt) >> r) & 1u) ztD[r] = zD[r];
+                }
+            }
+            zfinD = zD;
+            if (lane < LAT) {
+#pragma unroll
+                for (int r = 0; r < FPW; ++r) { const float dz = zD[r] - ztD[r]; fb0[r * FB_STRIDE + FB_LT + lane] = dz * dz; }
+            }
+            const Q4 cur = {cvs.x, cvs.y, cvs.z, cvs.w};
+            trk = tracker_finish(as, fb, rs, E, cur, step_shift);
+            for (int base = 16; base < Emax; base += 16) make_tracker(as, fb, gfi, tmask, E, base + b, cur, gft, step_shift, my_bad); // (uniform, rare)
             es_prev = 10000000.f; es_act = true; es_iters = 0;
             wave_sync();
         }
@@ -1142,9 +1228,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         const f4 g = add_halves(acc0 + acc1) + a.ctmp * (zD - ztD);
         STAMP(8);
         if (DBG_DUMP && a.dbg && iter == 0 && lane < LAT) {
+            int ld = lane;
+            asm volatile("" : "+v"(ld)); // (opaque: the four 64-bit addresses of this once-per-launch dump are not to be formed ahead of the loop and held across it)
 #pragma unroll
             for (int r = 0; r < FPW; ++r)
-                if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + lane] = g[r];
+                if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + ld] = g[r];
         }
 #ifdef W4_ABLATE_ADAM
         zD = zD - 1e-6f * g;
@@ -1197,6 +1285,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
     const auto& ae = step_args_of<SEQ>(a, lds);
+    // frames that failed the input screening: what the reference returns for them (include/dragposer.h: DP_STATUS_*) -- everything NaN when the
+    // state was bad; z and the loss NaN when the targets were, and the pose results too unless the frame stopped after its first pass
+    asm volatile("" : "+s"(bad_state), "+s"(bad_tgt)); // (opaque here: what the epilogue derives from them per lane is not to be computed ahead of the loop and held across it)
+    const unsigned pois_z = bad_state | bad_tgt, pois_all = bad_state | ((EARLY || ae.n_iter == 1) ? 0u : bad_tgt);
     int row0 = SEQ ? step * nB : 0; // SEQ: this step's slab of the per-step output arrays
     int gfo = row0 + gfi;
     // SEQ: whatever the stores' addresses are made of is opaque per step -- the compiler otherwise hoists the step-invariant 64-bit
@@ -1222,8 +1314,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         out_consts(lds + L_OC + 20 * b, item_eA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, item_eB, pc.kindB, oA, oB);
         if (fvalid || SEQ) { // (SEQ: the clamped copies of a ragged tail keep their own state consistent; their stores are skipped below)
             const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
-            w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY); // (SEQ: the copies re-store the last valid frame's rows, same values)
-            w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY);
+            w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY, (pois_all >> i) & 1u, (pois_z >> i) & 1u); // (SEQ: the copies re-store the last valid frame's rows, same values)
+            w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY, (pois_all >> i) & 1u, (pois_z >> i) & 1u);
         }
     }
     SQ_STAMP(2);
@@ -1231,13 +1323,22 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #pragma unroll
         for (int r = 0; r < FPW; ++r) {
             if (f0 + r < nB) {
-                if (ae.z && (!SEQ || step == ae.seq.n_steps - 1)) GM(ae.z)[(size_t)(f0_e + r) * LAT + lane_e] = EARLY ? zfinD[r] : zD[r];
-                if (ae.z_pre) GM(ae.z_pre)[(size_t)(row0 + f0_e + r) * LAT + lane_e] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
-                if (SEQ) GM(ae.seq.hist)[(size_t)(row0 + f0_e + r) * (LAT + 3 + ae.seq.n_heights) + lane_e] = fb0[r * FB_STRIDE + FB_ZPRE + lane];
+                if (ae.z && (!SEQ || step == ae.seq.n_steps - 1)) GM(ae.z)[(size_t)(f0_e + r) * LAT + lane_e] = poisoned((pois_z >> r) & 1u, EARLY ? zfinD[r] : zD[r]);
+                if (ae.z_pre) GM(ae.z_pre)[(size_t)(row0 + f0_e + r) * LAT + lane_e] = poisoned((pois_all >> r) & 1u, fb0[r * FB_STRIDE + FB_ZPRE + lane]);
+                if (SEQ) GM(ae.seq.hist)[(size_t)(row0 + f0_e + r) * (LAT + 3 + ae.seq.n_heights) + lane_e] = poisoned((pois_all >> r) & 1u, fb0[r * FB_STRIDE + FB_ZPRE + lane]);
             }
         }
     }
     if (optimise && ae.iters && lane < FPW && f0 + lane < nB) GM(ae.iters)[row0 + f0_e + lane_e] = EARLY ? es_iters : ae.n_iter;
+    if (ae.status) { // (uniform)
+        unsigned nonfin = pois_z; // bit r: the latent returned for frame f0 + r is not finite
+#pragma unroll
+        for (int r = 0; r < FPW; ++r) nonfin |= (__ballot(optimise && lane < LAT && !(fabsf(EARLY ? zfinD[r] : zD[r]) <= 3.0e38f)) != 0ull ? 1u : 0u) << r;
+        if (!optimise) nonfin = bad_state; // (dp_forward returns no latent: its frame results are NaN exactly when the state was refused)
+        if (lane < FPW && f0 + lane < nB)
+            GM(ae.status)[row0 + f0_e + lane_e] = (int)(((nonfin >> lane) & 1u) * DP_STATUS_NONFINITE_RESULT + ((bad_state >> lane) & 1u) * DP_STATUS_BAD_STATE +
+                                                        ((bad_tgt >> lane) & 1u) * DP_STATUS_BAD_TARGETS);
+    }
     SQ_STAMP(3);
     if (SEQ) { // the rest of run()'s epilogue (drag_pose.py:369-391), one lane per sequence: dp_sequence_advance's arithmetic
         wave_sync();
@@ -1258,17 +1359,18 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                     dsp[k] += adj;
                 }
             }
-            if (ae.seq.pos_ret && fvalid) { gfloat* o = GM(ae.seq.pos_ret) + (size_t)gfo * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; }
+            const bool pl = (pois_all >> i) & 1u; // (the state in the frame block stays finite; what leaves the kernel is the reference's NaN)
+            if (ae.seq.pos_ret && fvalid) { gfloat* o = GM(ae.seq.pos_ret) + (size_t)gfo * 3; o[0] = poisoned(pl, gp[0]); o[1] = poisoned(pl, gp[1]); o[2] = poisoned(pl, gp[2]); }
             if (fvalid) {
                 gfloat* o = GM(ae.seq.hist) + (size_t)gfo * (LAT + 3 + ae.seq.n_heights) + LAT;
-                o[0] = dsp[0]; o[1] = dsp[1]; o[2] = dsp[2];
-                for (int h = 0; h < ae.seq.n_heights; ++h) o[3 + h] = fb[FB_SPOS + 3 * ae.seq.height_joints[h] + 1] + gp[1];
+                o[0] = poisoned(pl, dsp[0]); o[1] = poisoned(pl, dsp[1]); o[2] = poisoned(pl, dsp[2]);
+                for (int h = 0; h < ae.seq.n_heights; ++h) o[3 + h] = poisoned(pl, fb[FB_SPOS + 3 * ae.seq.height_joints[h] + 1] + gp[1]);
             }
             *(f4*)(fb + FB_GPOS) = f4{gp[0], gp[1], gp[2], 0.f};
             *(f4*)(fb + FB_CUR) = qw; // drag_pose.py:371
             if (step == ae.seq.n_steps - 1 && fvalid) {
-                gfloat* o = GM(ae.seq.global_pos) + (size_t)gfi_e * 3; o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
-                gfloat* oq = GM(ae.seq.global_rot) + (size_t)gfi_e * 4; oq[0] = qw.x; oq[1] = qw.y; oq[2] = qw.z; oq[3] = qw.w;
+                gfloat* o = GM(ae.seq.global_pos) + (size_t)gfi_e * 3; o[0] = poisoned(pl, gp[0]); o[1] = poisoned(pl, gp[1]); o[2] = poisoned(pl, gp[2]);
+                gfloat* oq = GM(ae.seq.global_rot) + (size_t)gfi_e * 4; oq[0] = poisoned(pl, qw.x); oq[1] = poisoned(pl, qw.y); oq[2] = poisoned(pl, qw.z); oq[3] = poisoned(pl, qw.w);
             }
         }
         wave_sync();
@@ -1276,6 +1378,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SQ_STAMP(4);
     ++step;
     } while (SEQ && step < a.seq.n_steps);
+    if (clk_on) { // (uniform)
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[0] = c1 - clk_c0; a.clk[1] = r1 - clk_r0; }
+    }
 #ifdef DP_SEQ_STAMPS
     if (SEQ && tid == 0 && blockIdx.x == 0 && a.loss) { // the accumulated stamps over the first floats of `loss`
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

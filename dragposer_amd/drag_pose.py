@@ -138,6 +138,12 @@ class DragPose:
         S, dev = self.S, self.device
         assert window % SAMPLE_STEP == 0
         if self.target_latent_buffer is None or self.target_latent_buffer.shape[1] != window + 1:
+            if self.target_latent_buffer is not None:
+                # a window CHANGED in the middle of a window restarts the window (a prediction is made this frame), as the native plug-in
+                # does (dp_unity.cpp): the reference indexes the re-allocated buffer with the old index -- an IndexError when the window
+                # shrank, rows of zeros until the next prediction when it grew -- and here the old index would make run_frames() ask
+                # for a stretch of <= 0 frames
+                self.current_index = 0
             self.target_latent_buffer = torch.zeros(S, window + 1, LATENT, device=dev)
         if self.current_index != 0 or self.temporal is None:  # no predictor: the buffer stays zero, use lambda_temporal = 0
             return
@@ -218,6 +224,7 @@ class DragPose:
         poses = torch.empty(T, S, 88, device=dev)
         gpos = torch.empty(T, S, 3, device=dev)
         iters = torch.empty(T, S, dtype=torch.int32, device=dev)
+        status = torch.empty(T, S, dtype=torch.int32, device=dev)
         # The reference predicts at current_index == 0 whatever lambda_temporal is (drag_pose.py:235-291), so the stretches between two
         # predictions are cut the same way with the pull term on or off; without a predictor there is nothing to pull towards and the
         # term is off in run() and here alike (the reference cannot run without one).
@@ -238,9 +245,10 @@ class DragPose:
                                        self.latent_buffer, self.displacement_buffer, self.heights_buffer, tuple(int(h) for h in height_indices),
                                        n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot), lambda_tmp=float(lambda_temporal) if pull else 0.0,
                                        stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot, min_loss_incr=min_loss_incr, adjust=adjust,
-                                       pose_ret=poses[t:t + n], pos_ret=gpos[t:t + n], iters=iters[t:t + n])
+                                       pose_ret=poses[t:t + n], pos_ret=gpos[t:t + n], iters=iters[t:t + n], status=status[t:t + n])
             t += n
             self.current_index = 0 if window == 0 else (self.current_index + n) % window
+        self.last_status = status  # [T,S] DP_STATUS_* bits (include/dragposer.h): non-zero where a frame's inputs were not finite
         return poses, gpos, iters
 
     def run(self, target_ee_pos, target_ee_rot, mask_joints, weights_joints, offsets=None, stop_eps_pos=1e-2,
@@ -278,6 +286,7 @@ class DragPose:
         self._flip ^= 1  # two result sets, alternated: `last` stays valid while the next frame runs
         if self._out[self._flip] is None:
             self._out[self._flip] = dict(iters=torch.empty(1, S, dtype=torch.int32, device=dev), loss=torch.empty(1, S, 3, device=dev),
+                                         status=torch.empty(1, S, dtype=torch.int32, device=dev),
                                          scratch=torch.empty(1, S, LATENT + 3 + len(height_indices), device=dev), z=torch.empty(S, LATENT, device=dev))
         o = self._out[self._flip]
         z_tgt = self.target_latent_buffer[:, self.current_index:]
@@ -287,9 +296,10 @@ class DragPose:
                                    self.latent_buffer, self.displacement_buffer, self.heights_buffer, tuple(int(h) for h in height_indices),
                                    n_iter=max_iter, lr=learning_rate, lambda_rot=float(lambda_rot), lambda_tmp=float(lambda_temporal) if pull else 0.0,
                                    stop_eps_pos=stop_eps_pos, stop_eps_rot=stop_eps_rot, min_loss_incr=min_loss_incr, adjust=adjust,
-                                   pose_ret=pose.unsqueeze(0), pos_ret=gpos.unsqueeze(0), iters=o["iters"], loss=o["loss"], scratch=o["scratch"])
+                                   pose_ret=pose.unsqueeze(0), pos_ret=gpos.unsqueeze(0), iters=o["iters"], loss=o["loss"], scratch=o["scratch"],
+                                   status=o["status"])
         o["z"].copy_(self.latent)  # (self.latent is advanced in place by the next frame; `last` must not move with it)
-        self.last = dict(iters=o["iters"][0], loss=o["loss"][0], z=o["z"], pose=pose, pos=gpos)
+        self.last = dict(iters=o["iters"][0], loss=o["loss"][0], z=o["z"], pose=pose, pos=gpos, status=o["status"][0])
         if verbose:
             l, it = self.last["loss"].cpu(), self.last["iters"].cpu()
             print(f"Loss sqrt(Pos): {l[:, 0].sqrt().mean():.5f} // Loss Rot: {l[:, 1].mean():.5f} // "

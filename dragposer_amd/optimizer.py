@@ -27,7 +27,17 @@ _OUT_SPECS = {  # name -> (trailing shape, dtype)
     "rot": ((NJ, 9), torch.float32),
     "loss": ((3,), torch.float32),
     "iters": ((), torch.int32),
+    "status": ((), torch.int32),  # DP_STATUS_* bits (include/dragposer.h)
 }
+_LAUNCH_SPECS = {  # results that are per launch, not per frame; only on request
+    "clock": ((2,), torch.int64),  # shader cycles / 100 MHz ticks of workgroup 0's iteration loop: sclk_ghz()
+}
+
+
+def sclk_ghz(clock):
+    """the shader clock (GHz) a launch ran at, from the `clock` result (a host synchronisation)"""
+    c = clock.cpu()
+    return float(c[0]) / float(c[1]) * 0.1 if int(c[1]) > 0 else float("nan")
 
 
 def _check(t, name, shape, dtype, device):
@@ -99,9 +109,12 @@ class LatentOptimizer:
         res = _lib.DpResult()
         tensors = {}
         for name in names:
-            shape, dtype = _OUT_SPECS[name]
-            t = out[name] if out is not None and name in out else torch.empty((B,) + shape, dtype=dtype, device=self.device)
-            setattr(res, name, _check(t, name, (B,) + shape, dtype, self.device))
+            if name in _LAUNCH_SPECS:
+                shape, dtype = _LAUNCH_SPECS[name]
+            else:
+                shape, dtype = (B,) + _OUT_SPECS[name][0], _OUT_SPECS[name][1]
+            t = out[name] if out is not None and name in out else torch.empty(shape, dtype=dtype, device=self.device)
+            setattr(res, name, _check(t, name, shape, dtype, self.device))
             tensors[name] = t
         return res, tensors
 
@@ -203,13 +216,13 @@ class LatentOptimizer:
 def _optimize_sequence(self, latent, tgt_pos, tgt_rot, tgt_root, w, tracked, z_tgt, z_tgt_strides, global_pos, global_rot, latent_buf, disp_buf,
                        heights_buf, height_joints, n_iter=100, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, lambda_rot=1.0, lambda_tmp=0.0,
                        stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5, adjust=None, pose_ret=None, pos_ret=None, iters=None,
-                       loss=None, scratch=None):
+                       loss=None, scratch=None, status=None):
     """T consecutive frames of S sequences in one launch (include/dragposer.h: dp_optimize_sequence): the optimise loop with the
     reference's while-condition and run()'s epilogue per frame, state carried on the device.  tgt_pos [T,S,22,3] / tgt_rot
     [T,S,22,9] dense per joint; tgt_root [T,S,3] or None (position targets are then tgt_pos + (tgt_root[t] - running global
     position), eval_drag.py:186-199); w [S,22,2], tracked [S,22]; z_tgt any fp32 device tensor addressed with `z_tgt_strides` =
     (floats between steps, floats between sequences).  `latent` [S,24], `global_pos`, `global_rot` and the three history
-    buffers are updated IN PLACE.  Returns dict(pose_ret [T,S,88], pos_ret [T,S,3], iters [T,S], loss [T,S,3])."""
+    buffers are updated IN PLACE.  Returns dict(pose_ret [T,S,88], pos_ret [T,S,3], iters [T,S], loss [T,S,3], status [T,S]: DP_STATUS_* bits)."""
     T, S = int(tgt_pos.shape[0]), int(tgt_pos.shape[1])
     dev = self.device
     H, NH = int(latent_buf.shape[1]), len(height_joints)
@@ -240,7 +253,8 @@ def _optimize_sequence(self, latent, tgt_pos, tgt_rot, tgt_root, w, tracked, z_t
     outs = {}
     res.world_rot = None
     for name, t, shape, dtype in (("pose_ret", pose_ret, (T, S, 88), torch.float32), ("pos_ret", pos_ret, (T, S, 3), torch.float32),
-                                  ("iters", iters, (T, S), torch.int32), ("loss", loss, (T, S, 3), torch.float32)):
+                                  ("iters", iters, (T, S), torch.int32), ("loss", loss, (T, S, 3), torch.float32),
+                                  ("status", status, (T, S), torch.int32)):
         t = t if t is not None else torch.empty(shape, dtype=dtype, device=dev)
         setattr(res, name, _check(t, name, shape, dtype, dev))
         outs[name] = t

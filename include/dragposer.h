@@ -43,11 +43,13 @@
 extern "C" {
 #endif
 
-#define DP_VERSION 400 /* 0.4.0: dp_auto_kernel added; Adam eps must be > 0.  ABI BREAK at 0.3.0 (stated late): dp_params grew the
-                          trailing `kernel` field then, so sizeof(dp_params) changed -- a caller COMPILED against 0.2 hands over a
-                          shorter struct and must be recompiled against this header (the library cannot tell; there is no size
-                          field), zeroing the struct first (`dp_params p = {0}`) so that fields added later read as their defaults.
-                          max_trackers ignored since 0.2, dp_temporal_* added in 0.2, dp_optimize_sequence in 0.3 */
+#define DP_VERSION 500 /* 0.5.0: ABI BREAK, the last one of this kind: dp_params and dp_result now START with `struct_size` (sizeof the
+                          struct as the caller compiled it), so a caller built against another version of this header is DETECTED
+                          (DP_ERR_INVALID with a message naming both sizes) instead of read past; fields appended later are read only
+                          when struct_size covers them and take their defaults (0 / NULL) otherwise.  dp_result grew `status` (per-frame
+                          health word) and `clock` (shader clock the launch ran at).  Use DP_PARAMS_INIT / DP_RESULT_INIT.
+                          History: 0.4.0 dp_auto_kernel, Adam eps must be > 0; 0.3.0 dp_params grew `kernel` (the break that went
+                          unstated), dp_optimize_sequence; 0.2 dp_temporal_*, max_trackers ignored */
 
 #define DP_NUM_JOINTS 22
 #define DP_LATENT 24
@@ -117,6 +119,9 @@ typedef struct dp_batch {
 } dp_batch;
 
 typedef struct dp_params {
+    unsigned struct_size; /* sizeof(dp_params) in the caller's translation unit (DP_PARAMS_INIT sets it).  The library refuses a
+                             value below the 0.5.0 size (a 0.4 caller's first word is n_iter <= 256: always refused) and reads no
+                             field beyond it */
     int n_iter;        /* max_iter; exactly n_iter iterations when early_stop == 0 (<= DP_MAX_ITERS) */
     float lr;          /* learning_rate */
     float beta1, beta2, eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8.  eps must be > 0 (DP_ERR_INVALID otherwise): torch accepts 0,
@@ -130,6 +135,7 @@ typedef struct dp_params {
     int kernel;        /* DP_KERNEL_AUTO / _W4 / _W16 (below).  Added in 0.3.0: see DP_VERSION for what that means to 0.2 callers.
                           dp_optimize_sequence ignores it (whole-sequence launches are DP_KERNEL_W4's) and implies early_stop = 1 */
 } dp_params;
+#define DP_PARAMS_INIT {(unsigned)sizeof(dp_params)} /* dp_params p = DP_PARAMS_INIT;  (every other field zero) */
 
 /* Two kernels implement dp_optimize (same operator, same outputs, within the tolerance stated in DESIGN.md):
  *   DP_KERNEL_W4   4 frames per wavefront, fp32 MFMA (v_mfma_f32_4x4x1): every launch shape, forward-only, whole sequences.
@@ -154,6 +160,8 @@ int dp_auto_kernel(const dp_ctx* ctx, int n_frames);
 /* Outputs, DEVICE pointers; any may be NULL.  All but z are those of the LAST forward pass
  * (the latent before the final Adam step), as the reference returns them (drag_pose.py:309-312). */
 typedef struct dp_result {
+    unsigned struct_size; /* sizeof(dp_result) in the caller's translation unit (DP_RESULT_INIT sets it) */
+    unsigned reserved0;   /* must be 0 (a pre-0.5 dp_result starts with the pointer `z`: its upper half lands here and is refused) */
     float* z;          /* [B][24] latent after the last Adam step (next frame's warm start) */
     float* z_pre;      /* [B][24] latent of the last forward pass (current_latent) */
     float* pose;       /* [B][88] decoder output: normalised-space unit quaternions, root incremental */
@@ -164,7 +172,23 @@ typedef struct dp_result {
     float* rot;        /* [B][22][9] global joint rotation matrices */
     float* loss;       /* [B][3]  loss_pos, lambda_rot*loss_rot, lambda_tmp*loss_tmp */
     int* iters;        /* [B]     iterations executed */
+    int* status;       /* [B]     0 or DP_STATUS_* bits (new in 0.5.0): the per-frame counterpart of the failure detection the
+                                  reference does not have -- there a NaN tracker sample silently poisons self.latent for good */
+    unsigned long long* clock; /* [2] (new in 0.5.0) shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) workgroup 0 spent in
+                                  its iteration loop: cycles / ticks x 0.1 = the shader clock in GHz the launch ran at (the chip lowers
+                                  it under full load; bench.py reports it as roofline.sclk_ghz) */
 } dp_result;
+#define DP_RESULT_INIT {(unsigned)sizeof(dp_result)} /* dp_result r = DP_RESULT_INIT;  (every pointer NULL) */
+/* dp_result.status bits.  A frame with a non-finite input cannot be optimised (the reference's loss is NaN on its first pass, its
+ * while-condition then fails -- every comparison with NaN is false --, and Adam writes NaN into self.latent: drag_pose.py:300-304,
+ * 342-344).  The kernels reproduce what the reference RETURNS for such a frame and say so here; frames that share a wavefront with
+ * it are not affected (tests/test_hip_status.py). */
+#define DP_STATUS_NONFINITE_RESULT 1 /* the returned latent z is not finite */
+#define DP_STATUS_BAD_STATE 2        /* z0 or cur_rot not finite, or beyond DP_INPUT_LIMIT in magnitude: every result of the frame is NaN */
+#define DP_STATUS_BAD_TARGETS 4      /* a tracked joint's target / weight, or z_tgt, not finite or beyond DP_INPUT_LIMIT: z and loss are
+                                        NaN; with early_stop (or n_iter == 1) the pose results are those of the warm start z0 after ONE
+                                        pass, as the reference returns them; without, NaN */
+#define DP_INPUT_LIMIT 1.0e4f        /* metres / weight units / latent units: keeps every intermediate of the loop finite in fp32 */
 
 int dp_version(void);
 const char* dp_last_error(const dp_ctx* ctx);
@@ -177,7 +201,7 @@ int dp_destroy(dp_ctx* ctx);
 
 int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* params, const dp_result* out, void* hip_stream);
 
-/* decode + FK only; `out` fields z, z_pre, loss, iters are ignored. */
+/* decode + FK only; `out` fields z, z_pre, loss, iters, clock are ignored (status: DP_STATUS_BAD_STATE where z or cur_rot was refused). */
 int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float* cur_rot, const dp_result* out, void* hip_stream);
 
 /* ---- per-frame epilogue of a sequence (reference: DragPose.run, drag_pose.py:369-402,414) -------------------------
@@ -232,13 +256,19 @@ typedef struct dp_seq_frames {   /* DEVICE pointers; T = n_steps */
 } dp_seq_frames;
 
 typedef struct dp_seq_results {  /* DEVICE pointers, per step; any but hist_scratch may be NULL */
+    unsigned struct_size; /* sizeof(dp_seq_results) as the caller compiled it (DP_SEQ_RESULTS_INIT), checked like dp_result's */
+    unsigned reserved0;   /* must be 0 */
     float* pose_ret;     /* [T][S][88] what run() returns (root channels = the normalised world rotation) */
     float* pos_ret;      /* [T][S][3]  returned global position */
     float* world_rot;    /* [T][S][4]  global rotation after the step (= the state's global_rot then) */
     int* iters;          /* [T][S]     iterations executed */
     float* loss;         /* [T][S][3]  losses of the frame's last executed iteration */
     float* hist_scratch; /* [T][S][24 + 3 + NH] floats of caller-owned scratch (the steps' history rows before they are appended) */
+    int* status;         /* [T][S]     DP_STATUS_* bits of every step (new in 0.5.0).  A sequence whose step t had a bad target returns that step's
+                                       pose from its warm start (one pass) and is DP_STATUS_BAD_STATE from step t + 1 on -- the reference's latent
+                                       is NaN from there (drag_pose.py:342-344); the other sequences of the launch are not affected */
 } dp_seq_results;
+#define DP_SEQ_RESULTS_INIT {(unsigned)sizeof(dp_seq_results)}
 
 /* latent [S][24]: in = the warm start of the first step, out = the latent after the last.  state: global_pos / global_rot
  * in and out, the three history buffers advanced by n_steps.  adjust: the joint-adjustment fields of dp_seq_step (its pointers

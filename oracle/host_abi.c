@@ -107,6 +107,10 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_re
     (void)stream;
     if (!ctx) return DP_ERR_INVALID;
     if (!in || !p) return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL batch/params");
+    /* the refusals of dp_host.cpp (take_params / take_result): a struct compiled against another header is detected by its size word */
+    if (p->struct_size < sizeof(dp_params) || p->struct_size > 4096u) return fail(ctx, DP_ERR_INVALID, "dp_optimize: dp_params.struct_size (pre-0.5 dragposer.h?)");
+    if (out && (out->struct_size < sizeof(dp_result) || out->struct_size > 4096u || out->reserved0 != 0u))
+        return fail(ctx, DP_ERR_INVALID, "dp_optimize: dp_result.struct_size (pre-0.5 dragposer.h?)");
     if (in->n_frames <= 0) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_frames must be positive");
     if (!in->z0 || !in->z_tgt || !in->cur_rot || !in->tgt_pos || !in->tgt_rot || !in->w || !in->tracked)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL input array");
@@ -121,7 +125,7 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_re
     float *z = s, *zp = z + (size_t)B * 24, *pose = zp + (size_t)B * 24, *dn = pose + (size_t)B * 88, *wd = dn + (size_t)B * 3, *wr = wd + (size_t)B * 3,
           *pos = wr + (size_t)B * 4, *rot = pos + (size_t)B * NJ * 3, *loss = rot + (size_t)B * NJ * 9, *dsp = loss + (size_t)B * 3;
     int* it = (int*)(dsp + (size_t)B * 3);
-    const dp_result none = {0};
+    const dp_result none = DP_RESULT_INIT;
     const dp_result* o = out ? out : &none;
     ora_optimize(ctx->m, B, in->z0, in->z_tgt, in->cur_rot, in->tgt_pos, in->tgt_rot, in->w, in->tracked, p->n_iter, p->lr, p->beta1, p->beta2,
                  p->eps, p->lambda_rot, p->lambda_tmp, p->early_stop, p->stop_eps_pos, p->stop_eps_rot, p->min_loss_incr, OUT_OR(o->z, z),
@@ -130,6 +134,13 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_re
     if (o->disp) /* de-normalised root-space displacement (metres), as dp_result.disp says */
         for (int b = 0; b < B; ++b)
             for (int k = 0; k < 3; ++k) o->disp[b * 3 + k] = dn[b * 3 + k] * (float)ctx->m->sd_d[k] + (float)ctx->m->mu_d[k];
+    if (o->status) /* (the restatement has no input screening: it reports what came out) */
+        for (int b = 0; b < B; ++b) {
+            int bad = 0;
+            for (int k = 0; k < 24; ++k) bad |= !isfinite(OUT_OR(o->z, z)[b * 24 + k]);
+            o->status[b] = bad ? DP_STATUS_NONFINITE_RESULT : 0;
+        }
+    if (o->clock) o->clock[0] = o->clock[1] = 0; /* no shader clock on a CPU */
     free(s);
     return DP_OK;
 }
@@ -139,6 +150,8 @@ int dp_forward(dp_ctx* ctx, int n_frames, const float* z, const float* cur_rot, 
     (void)stream;
     if (!ctx) return DP_ERR_INVALID;
     if (n_frames <= 0 || !z || !cur_rot || !out) return fail(ctx, DP_ERR_INVALID, "dp_forward: bad arguments");
+    if (out->struct_size < sizeof(dp_result) || out->struct_size > 4096u || out->reserved0 != 0u)
+        return fail(ctx, DP_ERR_INVALID, "dp_forward: dp_result.struct_size (pre-0.5 dragposer.h?)");
     const int B = n_frames;
     float* s = (float*)malloc(sizeof(float) * (size_t)B * (88 + 3 + 3 + 4 + NJ * 3 + NJ * 9));
     float *pose = s, *dn = pose + (size_t)B * 88, *wd = dn + (size_t)B * 3, *wr = wd + (size_t)B * 3, *pos = wr + (size_t)B * 4, *rot = pos + (size_t)B * NJ * 3;

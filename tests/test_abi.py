@@ -24,18 +24,46 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.dp_version() == 400
+    assert lib.dp_version() == 500
 
 
-def test_struct_layouts_match_header_sizes():
+def test_struct_layouts_match_header_sizes(tmp_path):
+    """the ctypes mirrors of _lib.py against the C compiler's own view of include/dragposer.h: sizeof every struct, offsetof the
+    fields the 0.5.0 size words guard (a binding that drifts from the header would otherwise only show up as garbage on the GPU)"""
+    import shutil
+    import subprocess
+
     ptr = C.sizeof(C.c_void_p)
     assert C.sizeof(_lib.DpModel) == 20 * ptr + 8  # 20 pointers + int (+pad)
     assert C.sizeof(_lib.DpBatch) == 8 + 7 * ptr
-    assert C.sizeof(_lib.DpParams) == 13 * 4
-    assert C.sizeof(_lib.DpResult) == 10 * ptr
+    assert C.sizeof(_lib.DpParams) == 14 * 4       # struct_size + 13 fields
+    assert C.sizeof(_lib.DpResult) == 8 + 12 * ptr  # struct_size, reserved0, 12 pointers
+    assert C.sizeof(_lib.DpSeqResults) == 8 + 7 * ptr
     assert C.sizeof(_lib.DpSeqState) == 5 * ptr + 10 * 4  # 5 pointers, history, n_heights, height_joints[8]
     assert C.sizeof(_lib.DpSeqStep) == 16 + 3 * ptr      # 2 ints + float (+pad), 3 pointers
     assert C.sizeof(_lib.DpFolded) == 4 * (40 * 24 + 40 + 60 * 40 + 60 + 92 * 60 + 92)
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc: sizes checked against the arithmetic above only")
+    pairs = [("dp_model", _lib.DpModel), ("dp_batch", _lib.DpBatch), ("dp_params", _lib.DpParams), ("dp_result", _lib.DpResult),
+             ("dp_seq_state", _lib.DpSeqState), ("dp_seq_step", _lib.DpSeqStep), ("dp_seq_frames", _lib.DpSeqFrames),
+             ("dp_seq_results", _lib.DpSeqResults), ("dp_folded", _lib.DpFolded), ("dp_temporal_layer", _lib.DpTemporalLayer),
+             ("dp_temporal_model", _lib.DpTemporalModel)]
+    fields = [("dp_params", _lib.DpParams, "n_iter"), ("dp_params", _lib.DpParams, "kernel"), ("dp_result", _lib.DpResult, "z"),
+              ("dp_result", _lib.DpResult, "iters"), ("dp_result", _lib.DpResult, "status"), ("dp_result", _lib.DpResult, "clock"),
+              ("dp_seq_results", _lib.DpSeqResults, "pose_ret"), ("dp_seq_results", _lib.DpSeqResults, "status"),
+              ("dp_seq_frames", _lib.DpSeqFrames, "z_tgt_seq"), ("dp_temporal_model", _lib.DpTemporalModel, "dec")]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "dragposer.h"\nint main(void) {\n'
+                   + "".join(f'printf("%zu\\n", sizeof({c}));\n' for c, _ in pairs)
+                   + "".join(f'printf("%zu\\n", offsetof({c}, {f}));\n' for c, _, f in fields)
+                   + 'dp_params p = DP_PARAMS_INIT; dp_result r = DP_RESULT_INIT; dp_seq_results q = DP_SEQ_RESULTS_INIT;\n'
+                     'printf("%u %u %u %d\\n", p.struct_size, r.struct_size, q.struct_size, p.n_iter + (r.z != 0) + (int)r.reserved0);\nreturn 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = subprocess.check_output([str(exe)]).decode().split("\n")
+    want = [str(C.sizeof(t)) for _, t in pairs] + [str(getattr(t, f).offset) for _, t, f in fields]
+    assert got[:len(want)] == want, list(zip([c for c, _ in pairs] + [c + "." + f for c, _, f in fields], got, want))
+    assert got[len(want)] == f"{C.sizeof(_lib.DpParams)} {C.sizeof(_lib.DpResult)} {C.sizeof(_lib.DpSeqResults)} 0"
 
 
 @pytest.mark.parametrize("wd", ["fp32", "bf16"])

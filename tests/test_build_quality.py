@@ -88,7 +88,9 @@ def test_w16_instantiations_keep_their_register_budget(tmp_path, src, one_wave):
     (name, n), = [(k, v) for k, v in notes.items() if "dp_w16_kernel" in k]
     assert 135 * 1024 <= n["lds"] <= 160 * 1024, (name, n)
     if one_wave:
-        assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
+        # no scratch memory; the early-stop unit parks two values in the accumulator half since the round-5 input screening (its loop
+        # is the same 2.5 k instructions with 2 more v_accvgpr_write: 0.1 %)
+        assert n["scratch"] == 0 and n["vspill"] <= (2 if "_es" in src else 0), (name, n)
     else:
         assert n["vgpr"] <= 256 and n["vspill"] <= 72, (name, n)
     text = out.read_text()

@@ -1,0 +1,168 @@
+"""GPU: non-finite inputs (a tracker drop-out that sends NaN, an Inf in the warm start) and dp_result.status.
+
+What the reference does (drag_pose.py:296-355, one frame at a time): the loss of the first pass is NaN, every comparison of its
+while-condition is then false so the loop ends after that ONE pass (the returned pose is the one decoded from the warm start), and
+Adam has written NaN into self.latent -- the next frame of that sequence, and every one after it, is NaN.  Nothing tells the caller.
+What must hold here: the same results for the affected frame, a status word that says so, and -- the part a batched kernel has to earn --
+the frames that share its wavefront are NOT affected (dp_w4's D <-> X transposes are matrix products with unit rows: NaN x 0 = NaN would
+carry one frame's NaN into its three neighbours; the kernel screens its inputs instead, dp_w4.hip "input screening")."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+ST_NONFINITE, ST_BAD_STATE, ST_BAD_TARGETS = 1, 2, 4
+PER_FRAME = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "rot", "loss", "iters", "status")
+
+
+def _batch(B=64, seed=4321):
+    from dragposer_amd.optimizer import to_device_batch
+
+    return to_device_batch(R.synth_inputs(R.OracleModel(), B, seed=seed), torch.device("cuda:0"))
+
+
+def _rows_equal(a, b, rows):
+    for k in PER_FRAME:
+        x, y = a[k][rows], b[k][rows]
+        assert torch.equal(x, y) or (torch.isnan(x.float()) == torch.isnan(y.float())).all() and torch.equal(torch.nan_to_num(x.float()), torch.nan_to_num(y.float())), k
+
+
+@pytest.mark.parametrize("kernel", ["w4", "w16"])
+@pytest.mark.parametrize("early", [False, True])
+def test_a_nan_target_stays_in_its_frame(kernel, early):
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    opt = LatentOptimizer(device="cuda:0")
+    d = _batch()
+    kw = dict(n_iter=50, lambda_tmp=0.02, kernel=kernel, outputs=PER_FRAME)
+    if early:
+        kw.update(stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5, n_iter=100)
+    clean = opt.optimize(**d, **kw)
+    bad = dict(d)
+    bad["tgt_pos"] = d["tgt_pos"].clone()
+    bad["tgt_pos"][5, 13, 1] = float("nan")        # a tracked joint (left hand) of frame 5
+    bad["tgt_pos"][9, 2, 0] = float("nan")         # an UNTRACKED joint of frame 9: never read by the reference, must not matter
+    bad["tgt_rot"] = d["tgt_rot"].clone()
+    bad["tgt_rot"][22, 0, 4] = float("inf")        # the root tracker's rotation target of frame 22
+    bad["w"] = d["w"].clone()
+    bad["w"][41, 21, 0] = 1.0e9                     # an absurd weight (beyond DP_INPUT_LIMIT): refused like a non-finite one
+    out = opt.optimize(**bad, **kw)
+    torch.cuda.synchronize()
+    hit = [5, 22, 41]
+    others = [i for i in range(64) if i not in hit]
+    _rows_equal(out, clean, others)                 # incl. frames 4, 6, 7 (frame 5's wave in dp_w4) and frame 9
+    assert (out["status"][others] == 0).all() and (clean["status"] == 0).all()
+    for f in hit:
+        assert int(out["status"][f]) == ST_NONFINITE | ST_BAD_TARGETS, (f, int(out["status"][f]))
+        assert torch.isnan(out["z"][f]).all() and torch.isnan(out["loss"][f]).all()
+        if early:  # the reference: one pass, then the while-condition fails; what it returns is the pose of the warm start
+            assert int(out["iters"][f]) == 1
+            fwd = opt.forward(d["z0"][f:f + 1], d["cur_rot"][f:f + 1], outputs=("pose", "pos", "rot", "world_rot"))
+            for k in ("pose", "pos", "rot", "world_rot"):  # (pose: normalised channels, 1 / std ~ 200 x the quaternion's rounding)
+                assert torch.allclose(out[k][f], fwd[k][0], atol=5e-4 if k == "pose" else 5e-6), k
+            assert torch.equal(out["z_pre"][f], d["z0"][f])
+        else:      # fifty passes: the NaN latent of the second pass onwards decodes to NaN
+            for k in ("pose", "pos", "rot", "world_rot", "disp", "z_pre"):
+                assert torch.isnan(out[k][f]).all(), k
+
+
+@pytest.mark.parametrize("kernel", ["w4", "w16"])
+def test_a_nonfinite_state_gives_nan_and_says_so(kernel):
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    opt = LatentOptimizer(device="cuda:0")
+    d = _batch()
+    kw = dict(n_iter=30, lambda_tmp=0.02, kernel=kernel, outputs=PER_FRAME, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5)
+    clean = opt.optimize(**d, **kw)
+    bad = dict(d)
+    bad["z0"] = d["z0"].clone(); bad["z0"][7, 3] = float("inf")
+    bad["cur_rot"] = d["cur_rot"].clone(); bad["cur_rot"][30, 0] = float("nan")
+    bad["z_tgt"] = d["z_tgt"].clone(); bad["z_tgt"][50, 23] = float("nan")   # a target, not the state
+    out = opt.optimize(**bad, **kw)
+    torch.cuda.synchronize()
+    others = [i for i in range(64) if i not in (7, 30, 50)]
+    _rows_equal(out, clean, others)
+    for f in (7, 30):
+        assert int(out["status"][f]) == ST_NONFINITE | ST_BAD_STATE
+        assert int(out["iters"][f]) == 1
+        for k in ("z", "pose", "pos", "rot", "loss", "world_rot"):
+            assert torch.isnan(out[k][f]).all(), (f, k)
+    assert int(out["status"][50]) == ST_NONFINITE | ST_BAD_TARGETS and torch.isfinite(out["pos"][50]).all() and torch.isnan(out["z"][50]).all()
+
+
+def test_forward_keeps_a_nan_latent_in_its_frame():
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    opt = LatentOptimizer(device="cuda:0")
+    d = _batch(32)
+    names = ("pose", "disp", "world_disp", "world_rot", "pos", "rot", "status")
+    clean = opt.forward(d["z0"], d["cur_rot"], outputs=names)
+    z = d["z0"].clone(); z[13, 0] = float("nan")
+    out = opt.forward(z, d["cur_rot"], outputs=names)
+    torch.cuda.synchronize()
+    others = [i for i in range(32) if i != 13]
+    for k in names:
+        assert torch.equal(out[k][others], clean[k][others]), k
+    assert int(out["status"][13]) == ST_NONFINITE | ST_BAD_STATE and torch.isnan(out["pos"][13]).all() and torch.isnan(out["pose"][13]).all()
+
+
+def test_a_tracker_dropout_poisons_its_own_sequence_only():
+    """Whole-sequence launches: sequence 2 loses a tracker sample at step 3.  The reference returns that frame's pose from the warm start
+    (one pass), has a NaN latent from then on and returns NaN for every later frame of THAT sequence; the sequences that share its
+    wavefront go on as if nothing had happened."""
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    T, S = 8, 6
+    m = R.OracleModel()
+    b = R.synth_inputs(m, T * S, seed=99)
+    idx = np.array(R.TRACK6)
+    w = np.array([R.W6[j] for j in R.TRACK6], np.float32)
+    tp = torch.tensor(b["tgt_pos"][:, idx]).reshape(T, S, 6, 3).cuda()
+    tR = torch.tensor(b["tgt_rot"][:, idx]).reshape(T, S, 6, 3, 3).cuda()
+    opt = LatentOptimizer(device="cuda:0")
+    kw = dict(stop_eps_pos=1e-4, stop_eps_rot=1e-2, max_iter=40, min_loss_incr=1e-5, learning_rate=1e-2, lambda_rot=1, lambda_temporal=0.0,
+              temporal_future_window=0)
+
+    def fresh():
+        dp = DragPose(opt, None, np.zeros(24), np.ones(24), n_sequences=S)
+        dp.set_initial_state(b["z0"][:S], np.zeros((S, 3), np.float32), b["cur_rot"][:S], np.zeros((S, 6), np.float32))
+        return dp
+
+    a, c = fresh(), fresh()
+    pa, ga, ia = a.run_frames(tp, tR, idx, w, **kw)
+    tpb = tp.clone(); tpb[3, 2, 4, :] = float("nan")
+    pc, gc, ic = c.run_frames(tpb, tR, idx, w, **kw)
+    torch.cuda.synchronize()
+    ok = [s for s in range(S) if s != 2]
+    assert torch.equal(pc[:, ok], pa[:, ok]) and torch.equal(gc[:, ok], ga[:, ok]) and torch.equal(ic[:, ok], ia[:, ok])
+    assert (a.last_status == 0).all() and (c.last_status[:, ok] == 0).all()
+    st = c.last_status[:, 2].tolist()
+    assert st[:3] == [0, 0, 0] and st[3] == ST_NONFINITE | ST_BAD_TARGETS and all(v == ST_NONFINITE | ST_BAD_STATE for v in st[4:]), st
+    assert torch.equal(pc[:3, 2], pa[:3, 2])
+    assert torch.isfinite(pc[3, 2]).all() and int(ic[3, 2]) == 1          # the warm start's pose, one pass
+    assert torch.isnan(pc[4:, 2]).all() and torch.isnan(gc[4:, 2]).all() and (ic[4:, 2] == 1).all()
+    assert torch.isnan(c.latent[2]).all() and torch.isfinite(c.latent[ok]).all()
+    for attr in ("latent", "current_global_pos", "current_global_rot", "latent_buffer", "displacement_buffer", "heights_buffer"):
+        assert torch.equal(getattr(a, attr)[ok], getattr(c, attr)[ok]), attr
+    # ... and the next launch of the poisoned sequence starts from its NaN latent: still NaN, still flagged, the others still untouched
+    pa2, _, _ = a.run_frames(tp[:2], tR[:2], idx, w, **kw)
+    pc2, _, _ = c.run_frames(tp[:2], tR[:2], idx, w, **kw)
+    assert torch.equal(pc2[:, ok], pa2[:, ok]) and torch.isnan(pc2[:, 2]).all() and (c.last_status[:, 2] == (ST_NONFINITE | ST_BAD_STATE)).all()
+
+
+def test_clock_word_reports_a_plausible_shader_clock():
+    from dragposer_amd.optimizer import LatentOptimizer, sclk_ghz
+
+    opt = LatentOptimizer(device="cuda:0")
+    d = _batch(4096)
+    for kernel in ("w4", "w16"):
+        for _ in range(3):
+            out = opt.optimize(**d, n_iter=50, kernel=kernel, outputs=("z", "clock"))
+        g = sclk_ghz(out["clock"])
+        assert 0.5 < g < 2.6, (kernel, g, out["clock"].tolist())

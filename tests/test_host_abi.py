@@ -73,7 +73,7 @@ def test_exports_every_symbol_of_the_header(lib):
     hdr = open(os.path.join(ROOT, "include", "dragposer.h")).read()
     for sym in set(re.findall(r"^(?:int|const char\*)\s+(dp_\w+)\s*\(", hdr, flags=re.M)):
         assert hasattr(lib, sym), sym
-    assert lib.dp_version() == 400
+    assert lib.dp_version() == 500
     assert "libdragposer_hostonly" not in open(os.path.join(ROOT, "dragposer_amd", "_lib.py")).read()  # the product does not know it
 
 
@@ -143,4 +143,31 @@ def test_argument_validation_and_status_codes(lib, golden_dir):
     lib.dp_optimize_sequence.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     lib.dp_optimize_sequence.restype = C.c_int
     assert lib.dp_optimize_sequence(ctx, 1, None, None, None, None, None, None, None) == _lib.DP_ERR_UNSUPPORTED
+    lib.dp_destroy(ctx)
+
+
+def test_a_struct_compiled_against_another_header_is_refused(lib, golden_dir):
+    """include/dragposer.h 0.5.0: dp_params / dp_result start with struct_size.  A 0.4 caller's dp_params starts with n_iter (<= 256)
+    and its dp_result with the pointer `z` -- both land in the size word (and reserved0) and are refused instead of read past."""
+    import ctypes as C
+
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    ctx, hm = _ctx(lib)
+    b, keep = _batch(g, 4)
+    p = _params(g["meta"])
+    r, arrs = _results(4)
+    assert p.struct_size == C.sizeof(_lib.DpParams) and r.struct_size == C.sizeof(_lib.DpResult) and r.reserved0 == 0
+    assert lib.dp_optimize(ctx, C.byref(b), C.byref(p), C.byref(r), None) == _lib.DP_OK
+    p.struct_size = 50  # a 0.4 dp_params: n_iter = 50 in the first word
+    assert lib.dp_optimize(ctx, C.byref(b), C.byref(p), C.byref(r), None) == _lib.DP_ERR_INVALID
+    assert b"struct_size" in lib.dp_last_error(ctx)
+    p.struct_size = C.sizeof(_lib.DpParams)
+    r.struct_size, r.reserved0 = 0x1a2b3c40, 0x7f12  # a 0.4 dp_result: the two halves of a device pointer
+    assert lib.dp_optimize(ctx, C.byref(b), C.byref(p), C.byref(r), None) == _lib.DP_ERR_INVALID
+    r.struct_size, r.reserved0 = C.sizeof(_lib.DpResult), 0
+    # the new result words: status (the restatement screens nothing: it reports what came out) and clock (zeros on a CPU)
+    st, ck = np.full(4, -1, np.int32), np.full(2, 7, np.uint64)
+    r.status, r.clock = st.ctypes.data, ck.ctypes.data
+    assert lib.dp_optimize(ctx, C.byref(b), C.byref(p), C.byref(r), None) == _lib.DP_OK
+    assert (st == 0).all() and (ck == 0).all()
     lib.dp_destroy(ctx)

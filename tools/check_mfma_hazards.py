@@ -19,10 +19,11 @@ import __graft_entry__ as G
 NEED = {"C": 2, "AB": 4, "R": 4, "V": 2}
 
 
-def isa(extra):
+def isa(extra, base_flags=None):
+    """the ISA of dp_w4.hip as $HIPCC (the compiler build() uses) generates it with the product's flags (or `base_flags`) + `extra`"""
     out = os.path.join(tempfile.mkdtemp(prefix="w4isa_"), "dp_w4.s")
-    flags = [f for f in G.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + list(extra)
-    subprocess.check_call(["hipcc", *flags, "-S", "--cuda-device-only", "-o", out, os.path.join(G.CSRC, "dp_w4.hip")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    flags = [f for f in (G.HIPCC_FLAGS if base_flags is None else base_flags) if f not in ("-shared", "-fPIC")] + list(extra)
+    subprocess.check_call([os.environ.get("HIPCC", "hipcc"), *flags, "-S", "--cuda-device-only", "-o", out, os.path.join(G.CSRC, "dp_w4.hip")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out).read()
 
 
@@ -92,7 +93,11 @@ def check(text):
 
 
 if __name__ == "__main__":
-    n_mfma, counts, bad = check(isa(sys.argv[1:]))
+    argv = sys.argv[1:]
+    base = None
+    if argv and argv[0] == "--flags":  # tools/build_variant_w4.sh: the variant's complete flag list instead of the product's
+        base, argv = argv[1].split(), argv[2:]
+    n_mfma, counts, bad = check(isa(argv, base))
     print(f"{n_mfma} MFMAs; dependent pairs checked: {counts}; violations: {len(bad)}")
     for b in bad[:20]:
         print("  ", b)

@@ -615,7 +615,8 @@ def main():
     for name in ("s1", "s3", "s4"):
         if name + "_f64" in todo:  # adds the reference's own float64 run to a committed fixture
             add_f64(name, gold, offsets, parents, args.workers)
-    for name, Bf in (("full1024", 1024), ("full4096", 4096)):  # BASELINE config 2 / the headline batch, whole, through the reference
+    # BASELINE config 2 / the headline batch / config 3's 8192-frame batch (round 5: whole, no longer a probe), through the reference
+    for name, Bf in (("full1024", 1024), ("full4096", 4096), ("full8192", 8192)):
         if name in todo:
             full_size_reference(name, Bf, 1234, gold, offsets, parents, args.workers)
     if "full_s3_1024" in todo:  # BASELINE config 4 at size: 3 trackers, 100 iterations, lambda_temporal of 3_trackers_config.json
