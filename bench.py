@@ -108,11 +108,21 @@ def measure_traffic(argv_tail, kernel_substr):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--traffic", "none"] + argv_tail
+                   "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--traffic", "none", "--precondition-ms", "0"] + argv_tail
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            # (its own session: on a timeout the whole group goes -- rocprofv3 AND the profiled child, which would otherwise keep the GPU busy
+            #  while this process takes its timings)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=180)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter} pass timed out (killed with its process group)"
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
             per = defaultdict(float)
             rows = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -137,13 +147,38 @@ def measure_traffic(argv_tail, kernel_substr):
     return (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, note
 
 
+def usable_cpus():
+    """the cores this process may actually run on: the affinity mask and the cgroup quota, not os.cpu_count() (the GPU box shows all 256 of
+    the host's and hands a one-GPU job 16 of them)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(batch_np, n_iter, budget_s=20.0):
-    """The oracle ("port") timed on this host: reference-shaped B=1 autograd + torch.optim.Adam
-    loop, 1 thread, on a bounded sample of the same workload."""
+    """The oracle ("port") timed on this host, as SURVEY.md 8(d) words it: (i) the reference-shaped B = 1 autograd + torch.optim.Adam loop on a
+    bounded sample of the same workload, with 1 thread (the headline `value`) and with every usable core; (ii) the same mathematics batched
+    over the 4096 frames on every usable core; plus the scalar C restatement on one core.  `batch_np`: the first frames of the GPU's batch."""
     from oracle import ref_torch as R
     from oracle.analytic import AnalyticOracle
 
     model = R.OracleModel()
+    ncpu = usable_cpus()
     torch.set_num_threads(1)
     args = [batch_np[k] for k in ("z0", "z_tgt", "cur_rot", "tgt_pos", "tgt_rot", "w", "tracked")]
     R.optimize_reference_shaped(model, *[a[:1] for a in args], n_iter)  # warm-up
@@ -154,25 +189,37 @@ def cpu_baseline(batch_np, n_iter, budget_s=20.0):
     dt = time.perf_counter() - t0
     out = dict(value=n / dt, unit="frames/s", cores=1, kind="port",
                sample=f"{n} frames x {n_iter} iters, batch-1 PyTorch autograd + torch.optim.Adam loop (as the reference runs), 1 thread")
-    # extra context: the scalar C restatement of the same math (analytic backward), one core
+    # (i) again with every usable core: torch's intra-op threads on 24..92-wide tensors (slower than one thread; stated, as SURVEY 8d asks)
+    torch.set_num_threads(ncpu)
+    R.optimize_reference_shaped(model, *[a[:1] for a in args], n_iter)
+    n, t0 = 0, time.perf_counter()
+    while n < 16 and time.perf_counter() - t0 < 6.0:
+        R.optimize_reference_shaped(model, *[a[n:n + 1] for a in args], n_iter)
+        n += 1
+    out["reference_shaped_all_cores_frames_per_s"] = n / (time.perf_counter() - t0)
+    out["reference_shaped_all_cores_sample"] = f"{n} frames, torch.set_num_threads({ncpu})"
+    # the scalar C restatement of the same math (analytic backward), one core
     A = AnalyticOracle(precision="f32")
     nb = min(512, len(args[0]))
     t0 = time.perf_counter()
     A.optimize(*[a[:nb] for a in args], n_iter)
     out["c_port_1core_frames_per_s"] = nb / (time.perf_counter() - t0)
-    # and the torch restatement batched over frames (what a CPU user gets by vectorising the reference), on the
-    # GPU box's CPU share
-    nt = max(1, min(16, os.cpu_count() or 1))
-    torch.set_num_threads(nt)
-    nb = min(1024, len(args[0]))
+    # (ii) the torch restatement batched over frames (what a CPU user gets by vectorising the reference), B = 4096 on every usable core
+    nb = min(4096, len(args[0]))
     R.optimize(model, *[a[:64] for a in args], 2)  # warm-up
     t0 = time.perf_counter()
     R.optimize(model, *[a[:nb] for a in args], n_iter)
     out["batched_torch_frames_per_s"] = nb / (time.perf_counter() - t0)
-    out["batched_torch_threads"] = nt
+    out["batched_torch_frames"] = nb
+    out["batched_torch_threads"] = ncpu
     torch.set_num_threads(1)
     out["host_cpus"] = os.cpu_count()
+    out["usable_cpus"] = ncpu
+    out["cpu_model"] = cpu_model_name()
     return out
+
+
+PRECONDITION_MS = 60.0  # of the measured launch, back to back, before the warm-up steps (see timed_pass)
 
 
 def main():
@@ -189,6 +236,11 @@ def main():
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
                     help="roofline.traffic: measure = two rocprofv3 --pmc child passes of this workload (N = 1 only, adds about a minute); file = the committed "
                          "PMC passes (profiles/); auto = measure when rocprofv3 is there and N = 1, else file")
+    ap.add_argument("--precondition-ms", type=float, default=PRECONDITION_MS,
+                    help="GPU-milliseconds of the measured launch run back to back before the warm-up steps, so that the timed steps run at the shader "
+                         "clock a busy GPU holds (DVFS: 2.08 GHz from idle, 2.39 GHz after ~25 ms of load, profiles/r05_clock_ramp.txt); 0 = off")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling block (north_star's 4096-frame batch, config 3's 8192) after the main pass")
+    ap.add_argument("--lib", default=None, help="diagnostic builds (tools/ab.sh): path of the library to load instead of dragposer_amd/lib/libdragposer_hip.so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -227,6 +279,10 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.lib:
+        from dragposer_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from dragposer_amd.optimizer import LatentOptimizer
 
     from dragposer_amd.sharding import pick_kernel, reduce_stats, shard_bounds
@@ -246,31 +302,48 @@ def main():
         batch = synth_on_device(opt, args.frames, 1234 + rank, device, mixed=s4)
         B, total_per_step = args.frames, args.frames * world
     names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters", "status", "clock")
-    out = opt.optimize(**batch, n_iter=N, outputs=names, kernel=args.kernel)
-    torch.cuda.synchronize()
+    from dragposer_amd.optimizer import sclk_ghz
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=args.kernel)
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # torch's current stream == the stream the kernel is launched on
-    for _ in range(args.steps):
-        opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=args.kernel)
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-    fpb, tpb, lds_bytes = opt.kernel_geometry()
-    from dragposer_amd.optimizer import sclk_ghz
+    def timed_pass(batch, kernel, steps, warmup):
+        """W untimed warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize on both sides.  Ahead of the warm-up the
+        device is PRECONDITIONED: the same launch back to back for --precondition-ms of GPU time.  Why: the shader clock is a DVFS state --
+        2.08 GHz on the first launches after idle, 2.14 after ~3 ms, the 2.38-2.40 GHz plateau after ~25 ms of sustained load, back down
+        after a 10 ms gap (profiles/r05_clock_ramp.txt) -- and 20 timed steps are 2.7 ms: without it the line reports the idle clock.
+        The semantics of `steps` / `warmup` are untouched; the line states the preconditioning (config.precondition_ms) and the clock the
+        last timed launch ran at (roofline.sclk_ghz).  Returns (wall seconds, kernel ms per step by HIP events, GHz, results)."""
+        out = opt.optimize(**batch, n_iter=N, outputs=names, kernel=kernel)
+        torch.cuda.synchronize()
+        if args.precondition_ms > 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
+            e1.record()
+            torch.cuda.synchronize()
+            per = max(e0.elapsed_time(e1) / 3.0, 1e-3)
+            for _ in range(min(20000, int(args.precondition_ms / per) + 1)):  # (no synchronisation from here to the timed region's own)
+                opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
+        for _ in range(warmup):
+            opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
+        barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()  # torch's current stream == the stream the kernel is launched on
+        for _ in range(steps):
+            opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, ev0.elapsed_time(ev1) / steps, sclk_ghz(out["clock"]), out
 
-    sclk = sclk_ghz(out["clock"])  # the shader clock the LAST timed launch ran at (dp_result.clock: workgroup 0's cycles / 100 MHz ticks)
+    dt, kern_ms, sclk, out = timed_pass(batch, args.kernel, args.steps, args.warmup)
+    fpb, tpb, lds_bytes = opt.kernel_geometry()
 
     # ---- parity on a sample (rank-local), reduced with the timing
     err_mm = float("nan")
@@ -289,6 +362,25 @@ def main():
     (dt, kern_ms, err_mm), _ = reduce_stats(dist, device, max_stats=[dt, kern_ms, err_mm if err_mm == err_mm else -1.0])
     if world > 1:  # every rank's own launch time, on stderr (rank 0's JSON line carries the maximum)
         print(f"[rank {rank}] kernel_ms {kern_ms_rank:.4f} frames {B}", file=sys.stderr, flush=True)
+
+    # ---- N > 1: the numbers north_star names, in the same process group, without the driver changing its command: ONE 4096-frame batch
+    #      (north_star) and ONE 8192-frame batch (BASELINE config 3) cut into contiguous shards, every shard in the kernel the largest one
+    #      gets (sharding.pick_kernel).  Expectation stated in DESIGN.md section 8: flat -- one GPU already runs 4096 frames at one wave per
+    #      SIMD, fewer frames per GPU leave SIMDs idle without shortening any wave's work.
+    strong = []
+    if world > 1 and not args.no_strong and args.total_frames == 0:
+        for total in (4096, 8192):
+            lo, hi = shard_bounds(total, world, rank)
+            kern = pick_kernel(opt, total, world)
+            sb = synth_on_device(opt, total, 1234, device, lo, hi, mixed=s4)
+            sdt, sk, sclk_s, _ = timed_pass(sb, kern, args.steps, args.warmup)
+            # every rank's own launch time: a one-hot vector summed over the ranks (the same small all-reduce as everything else here)
+            (sdt, sk_max), per_rank = reduce_stats(dist, device, max_stats=[sdt, sk], sum_stats=[sk if r == rank else 0.0 for r in range(world)])
+            sfpb = opt.kernel_geometry()[0]
+            strong.append({"frames_total": total, "frames_per_gpu": shard_bounds(total, world, 0)[1], "kernel": kern,
+                           "value": total * args.steps / sdt, "unit": "frames/s", "ms_per_step": sdt / args.steps * 1e3,
+                           "kernel_ms_max": sk_max, "kernel_ms_per_rank": per_rank, "sclk_ghz_rank0": sclk_s,
+                           "workgroup_frames": sfpb, "scaling": "strong"})
 
     if rank == 0:
         value = total_per_step * args.steps / dt
@@ -314,13 +406,15 @@ def main():
                                      f"{'S4' if s4 else 'S1'}: {B} synthetic frames per GPU") +
                                     (f", 1-6 of the trackers [0,3,7,13,17,21] per frame (masked loss), bf16-rounded decoder weights, {N} Adam iters/frame (BASELINE config 5)"
                                      if s4 else f", 6 trackers [0,3,7,13,17,21], {N} Adam iters/frame, fp32 (BASELINE north_star: 4096-frame batch)")),
-                       "frames_per_gpu": Bk, "frames_total": total_per_step, "iters": N,
+                       "frames_per_gpu": Bk, "frames_total": total_per_step, "iters": N, "precondition_ms": args.precondition_ms,
                        "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA,
                          "traffic": traffic if traffic is not None else (pmc_traffic_bytes(Bk, N) if args.traffic != "none" else None),
                          "traffic_note": (traffic_note if traffic is not None else
-                                          f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes ({PMC_FILE}, same command)")
+                                          "traffic not collected (--traffic none)" if args.traffic == "none" else
+                                          f"not measured in this run: HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes ({PMC_FILE}, same command)"
+                                          if pmc_traffic_bytes(Bk, N) is not None else "no committed counters for this configuration (they exist for 4096 frames x 50 iterations)")
                                          + f"; algorithmic {Bk * 2326:.3g}",
                          # the roofline's 157.3 TF is the fp32 matrix rate AT 2.4 GHz; the chip holds less than that with every SIMD on the matrix pipe
                          # (profiles/r05_clock_ramp.txt).  frac above stays against the full 157.3; this is the same work against the clock actually held
@@ -332,8 +426,10 @@ def main():
                          "hbm_algorithmic_GBps": Bk * 2326 / (kern_ms * 1e-3) / 1e9},
             "parity_p99_mm_vs_oracle": err_mm,  # 256 frames x 22 joints vs the C oracle (fp32)
         }
+        if strong:
+            res["strong"] = strong
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
-            cpu = {k: v[:1024].cpu().numpy() for k, v in batch.items()}
+            cpu = {k: v[:4096].cpu().numpy() for k, v in batch.items()}
             res["cpu_baseline"] = cpu_baseline(cpu, N)
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DRAGPOSER_LIB", os.path.join(HERE, "lib", "libdragposer_hip.so"))  # override: diagnostic builds
+LIB_PATH = os.path.join(HERE, "lib", "libdragposer_hip.so")  # (the product reads no environment variable; diagnostic tools pass their build's
+                                                              #  path explicitly: bench.py --lib, tools/_diaglib.py)
 
 DP_OK = 0
 DP_ERR_INVALID = -1
@@ -177,6 +178,7 @@ def load(path=None):
     # private test hooks (not part of include/dragposer.h)
     lib.dp_optimize_debug.argtypes = [C.c_void_p, C.POINTER(DpBatch), C.POINTER(DpParams), C.POINTER(DpResult),
                                       C.c_void_p, C.c_void_p]
+    lib.dp_temporal_debug_force_variant.argtypes = [C.c_void_p, C.c_int]
     lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f, C.POINTER(C.c_uint)]
     lib.dp_debug_items.argtypes = [C.POINTER(DpModel), C.c_void_p]
     lib.dp_debug_pack_w16.argtypes = [C.POINTER(DpFolded), C.POINTER(DpModel), C.c_void_p, C.c_void_p, C.c_void_p]

@@ -12,7 +12,7 @@
 // skeleton), which is what makes whole (tile, step) blocks structurally zero and skippable.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DP_HD __host__ __device__
 #else
 #define DP_HD

@@ -476,8 +476,8 @@ thread_local std::string g_terr;
 
 struct dp_temporal {
     int device = -1, n_cu = 256;
-    int forced_variant = 0; // DP_TEMPORAL_VARIANT in the environment at dp_temporal_create: 21, 41 or 42 (waves per SIMD, sequences
-                            // per workgroup) = that kernel variant whatever the batch (tests)
+    int forced_variant = 0; // dp_temporal_debug_force_variant (private test hook, below): 21, 41 or 42 (waves per SIMD, sequences
+                            // per workgroup) = that kernel variant whatever the batch; 0 = chosen from the batch (the product)
     float* d_w = nullptr;
     TArgs args{};
     std::string err;
@@ -592,7 +592,6 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, DP_ERR_DEVICE, "dp_temporal_create: hipSetDevice failed");
     dp_temporal* t = new dp_temporal;
     t->device = device;
-    if (const char* e = std::getenv("DP_TEMPORAL_VARIANT")) t->forced_variant = std::atoi(e);
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->n_cu = cu; }
     hipError_t e = hipMalloc((void**)&t->d_w, buf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->d_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -617,6 +616,14 @@ extern "C" int dp_temporal_destroy(dp_temporal* t)
     if (t->d_w) (void)hipFree(t->d_w);
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
     delete t;
+    return DP_OK;
+}
+
+// private test hook (not in include/dragposer.h; the product reads no environment variable): pin the kernel variant of later predictions
+extern "C" int dp_temporal_debug_force_variant(dp_temporal* t, int variant)
+{
+    if (!t || (variant != 0 && variant != 21 && variant != 41 && variant != 42)) return DP_ERR_INVALID;
+    t->forced_variant = variant;
     return DP_OK;
 }
 

@@ -131,6 +131,12 @@ class NativeTemporal:
             raise _lib.DragPoserError(rc, msg.decode() if msg else "")
         self._h = h
 
+    def _force_variant(self, variant):
+        """tests only: pin the kernel variant (21 / 41 / 42: waves per SIMD, sequences per workgroup; 0: chosen from the batch)"""
+        rc = self._lib.dp_temporal_debug_force_variant(self._h, int(variant))
+        if rc != 0:
+            raise ValueError(f"dp_temporal_debug_force_variant({variant}) -> {rc}")
+
     def predict(self, latent_buffer, displacement_buffer, heights_buffer, window, out=None):
         """history buffers [S, H, 24] / [S, H, 3] / [S, H, n_heights] (fp32, on the device, newest entry last)
         -> target_latent_buffer [S, window + 1, 24] (row current_index of it is the frame's z_tgt)"""

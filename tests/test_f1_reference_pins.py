@@ -25,7 +25,7 @@ from dragposer_amd.eval_drag import eval_pos_error, result_to_bvh, synthesize_ta
 from oracle import ref_torch as R
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLIPS = ["f1_clip6", "f1_clip3", "f1_clip6_t", "f1_clip3_t"]
+CLIPS = ["f1_clip6", "f1_clip3", "f1_clip4", "f1_clip6_t", "f1_clip3_t", "f1_clip4_t"]
 
 
 def load(golden_dir, name):
@@ -72,7 +72,7 @@ def test_preprocessing_equals_the_references_test_motion_data(golden_dir, stats,
     np.testing.assert_allclose(np.abs(m["dqs"].astype(np.float64)).sum(0), g["dqs_colabs"], rtol=1e-4, atol=0.5)
 
 
-@pytest.mark.parametrize("name", ["f1_clip6", "f1_clip3", "f1_example"])
+@pytest.mark.parametrize("name", ["f1_clip6", "f1_clip3", "f1_clip4", "f1_example"])
 def test_targets_equal_the_references_per_frame_synthesis(golden_dir, stats, name):
     """eval_drag.py:164-202: what DragPose.run received as target_ee_pos / target_ee_rot, frame by frame.  The position targets are
     relative to the RUNNING global position (recorded in the fixture): ours are root-relative + (target root - running position)."""

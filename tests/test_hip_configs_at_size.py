@@ -133,3 +133,69 @@ def test_kernels_agree_with_each_other_at_size(opts, dev, golden_dir, name):
     e = _mm(a4, a16)
     print(f"{name}: w4 vs w16 mean {e.mean():.5f} mm, p99 {np.percentile(e, 99):.5f}, max {e.max():.4f}, frames above 0.05 mm: {np.nonzero(e.max(1) > 0.05)[0].tolist()}")
     assert np.percentile(e, 99) <= 0.01 and (e.max(axis=1) > 0.05).sum() <= 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3: ONE batch of 8192 frames (recipe S1), sharded 8 x 1024 across the GPUs of a node.  Round 5: the WHOLE batch through the
+# real reference in fp32 and fp64 (tests/golden/full8192.npz, tools/make_goldens.py --only full8192: 2 x 12 minutes on 6 cores), so "is this
+# a frame without an implementation-independent answer?" is answered by the reference's own pair on every frame -- the repo's C-oracle pair
+# no longer fills in anywhere -- and the round-4 escape ("any distance, if the final loss is not above the oracle's") is gone.
+# The tolerance enforced is the one BASELINE.md section 3 now states for S1 / S2:
+#   * >= 99.9 % of the frames within 0.05 mm of the reference's fp32 run (max over the 22 joints), NO frame beyond 5 mm;
+#   * every frame beyond 0.05 mm is flagged by the reference's own fp32 / fp64 pair (> 0.02 mm apart) or shows one of the two mechanisms of
+#     tests/sensitivity.py (a LeakyReLU pre-activation within rounding of zero on its trajectory; a gradient component within rounding of
+#     zero under Adam's first steps);
+#   * there are at most 2 x (the pair's own count) + 2 of them.
+@pytest.mark.parametrize("how", ["one_launch", "shards_of_1024"])
+def test_config3_whole_batch_against_the_reference(opts, dev, golden_dir, how):
+    """one_launch: the 8192 frames on ONE GPU (DP_KERNEL_AUTO: dp_w16 beyond 4096 frames).  shards_of_1024: the eight contiguous shards a
+    node's eight ranks get (dragposer_amd.sharding.shard_bounds), each in its own launch with the kernel sharding.pick_kernel pins for the
+    batch (dp_w4 at 1024 frames per GPU) -- every rank's slice held to the reference's rows of that slice, which is what
+    tests/test_multi_gpu.py holds a real rank to when a node is there."""
+    from dragposer_amd.optimizer import to_device_batch
+    from dragposer_amd.sharding import pick_kernel, shard_bounds
+
+    ref = R.load_golden(os.path.join(golden_dir, "full8192.npz"))
+    mt = ref["meta"]
+    B = mt["B"]
+    assert B == 8192 and mt["n_iter"] == 50
+    b = R.synth_inputs(R.OracleModel(), B, seed=mt["seed"])
+    assert np.abs(b["tgt_pos"][:, T6] - ref["tgt_pos6"]).max() < 1e-5
+    b["tgt_pos"][:, T6], b["tgt_rot"][:, T6] = ref["tgt_pos6"], ref["tgt_rot6"]
+    assert _digest(b) == mt["digest"], "the recipe's inputs are not the ones the reference was run on"
+    opt = opts["none"]
+    if how == "one_launch":
+        o = {k: v.cpu().numpy() for k, v in opt.optimize(**to_device_batch(b, dev), n_iter=50, lambda_tmp=mt["lambda_tmp"]).items()}
+        assert opt.kernel_geometry()[0] == 64  # dp_w16, one wave of 16 frames per SIMD
+    else:
+        kern = pick_kernel(opt, B, 8)
+        assert kern == "w4"
+        parts = []
+        for r in range(8):
+            lo, hi = shard_bounds(B, 8, r)
+            parts.append({k: v.cpu().numpy() for k, v in
+                          opt.optimize(**to_device_batch({k: b[k][lo:hi] for k in KEYS}, dev), n_iter=50, lambda_tmp=mt["lambda_tmp"], kernel=kern).items()})
+        o = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    e = _mm(o["pos"], ref["pos"])
+    err = e.max(axis=1)
+    flag = np.zeros(B, bool)
+    flag[ref["sens_frames"]] = True
+    # on a frame the reference's own pair flags, its fp64 run is as good an answer as its fp32 run
+    e64 = np.full(B, np.inf)
+    e64[ref["sens_frames"]] = _mm(o["pos"][ref["sens_frames"]], ref["pos_f64_sens"]).max(axis=1)
+    err = np.minimum(err, e64)
+    bad = np.nonzero(err > 0.05)[0]
+    ok, kink, tiny = explained(b, bad, 50, mt["lambda_tmp"], flagged=ref["sens_frames"])
+    print(f"config 3, {how}: 8192 frames vs the reference's fp32 run: mean {e.mean():.5f} mm, p99 {np.percentile(e, 99):.5f}, max {err.max():.3f}; above 0.05 mm: "
+          f"{bad.tolist()} ({np.round(err[bad], 3).tolist()} mm; smallest |pre-activation| {kink.tolist()}, smallest |dL/dz_k| {tiny.tolist()}); the reference's "
+          f"own pair parts ways on {ref['sens_frames'].tolist()} ({np.round(ref['ref32_vs_ref64_mm'][ref['sens_frames']], 3).tolist()} mm)")
+    assert (err <= 0.05).mean() >= 0.999 and err.max() <= 5.0, ((err > 0.05).sum(), err.max())
+    assert ok.all() and len(bad) <= 2 * len(ref["sens_frames"]) + 2, (bad, kink, tiny)
+    good = err <= 0.05
+    assert e[good].mean() <= 0.002 and np.percentile(e[good], 99) <= 0.005
+    np.testing.assert_allclose(o["loss"][good], ref["loss_last"][good], rtol=2e-3, atol=1e-8)
+    assert (o["iters"] == 50).all() and (o["status"] == 0).all()
+    if how == "shards_of_1024":  # per rank: the bar holds on every slice, not just on the whole
+        for r in range(8):
+            lo, hi = shard_bounds(B, 8, r)
+            assert (err[lo:hi] <= 0.05).mean() >= 0.997, (r, (err[lo:hi] > 0.05).sum())

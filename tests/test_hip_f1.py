@@ -55,7 +55,7 @@ def _run_cli(g, tmp_path, per_frame=False):
     return E.main(argv + ["--keep-frames"])[0]
 
 
-@pytest.mark.parametrize("name", ["f1_clip6", "f1_clip3", "f1_clip6_t", "f1_clip3_t"])
+@pytest.mark.parametrize("name", ["f1_clip6", "f1_clip3", "f1_clip4", "f1_clip6_t", "f1_clip3_t", "f1_clip4_t"])
 def test_cli_against_the_reference_run_of_the_clip(golden_dir, tmp_path, name):
     g = load(golden_dir, name)
     raw = np.load(R.DEFAULT_MODEL)

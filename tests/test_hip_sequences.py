@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 STRICT = 16  # closed-loop frames held to the tight bounds (see test_sequences_track_the_reference_state_machine)
 
 
-@pytest.mark.parametrize("name", ["seq6", "seq3"])
+@pytest.mark.parametrize("name", ["seq6", "seq3", "seq4"])
 def test_sequences_track_the_reference_state_machine(golden_dir, name):
     from dragposer_amd.drag_pose import DragPose
     from dragposer_amd.optimizer import LatentOptimizer
@@ -56,7 +56,7 @@ def test_sequences_track_the_reference_state_machine(golden_dir, name):
         np.testing.assert_allclose(dp.latent_buffer[k].cpu().numpy()[:n], g[f"final_latent_buffer_{k}"][:n], atol=2e-3)
 
 
-@pytest.mark.parametrize("name", ["seq6", "seq3"])
+@pytest.mark.parametrize("name", ["seq6", "seq3", "seq4"])
 def test_teacher_forced_frames_match_the_reference(golden_dir, name):
     """Every frame of the reference's recorded sequences as an independent problem: inputs are the state the REFERENCE
     had before the frame (its latent, global rotation, temporal target), outputs are compared with the state it had
@@ -163,7 +163,7 @@ def test_eval_drag_cli_on_bvh_clip(tmp_path):
     assert res["mean_iters"] < 60
 
 
-@pytest.mark.parametrize("name", ["seq6", "seq3", "sequ"])
+@pytest.mark.parametrize("name", ["seq6", "seq3", "seq4", "sequ"])
 def test_frame_loop_on_the_device_equals_per_frame_calls(golden_dir, name):
     """DragPose.run_frames (dp_optimize_sequence: the frame loop inside one launch per stretch between two temporal predictions)
     against T calls of DragPose.run, on the reference-recorded sequences with their temporal predictor and joint adjustment:

@@ -39,10 +39,9 @@ def _torch_block(model, means, stds, lat, disp, hts, window):
 # 41 = two workgroups per CU, 42 = two per CU with two sequences each (many sequences of at most 16 tokens)
 @pytest.mark.parametrize("variant", [21, 41, 42])
 @pytest.mark.parametrize("window", [0, 16, 60])
-def test_native_predictor_matches_nn_transformer_at_full_size(window, variant, monkeypatch):
+def test_native_predictor_matches_nn_transformer_at_full_size(window, variant):
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
 
-    monkeypatch.setenv("DP_TEMPORAL_VARIANT", str(variant))  # read at dp_temporal_create
 
     torch.manual_seed(3)
     model = TemporalPredictor().eval()  # 3 + 3 layers, d_model 48, 4 heads, feed-forward 2048 (train_temporal.py:17-37)
@@ -55,6 +54,7 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window, variant, m
     lat, disp, hts = torch.randn(S, H, 24, generator=g), 0.02 * torch.randn(S, H, 3, generator=g), 1.0 + 0.3 * torch.randn(S, H, 6, generator=g)
     want = _torch_block(model, means, stds, lat, disp, hts, window)
     nat = NativeTemporal(model, means, stds, device="cuda:0")
+    nat._force_variant(variant)  # (private test hook: dp_temporal_debug_force_variant)
     got = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
     assert got.shape == (S, window + 1, 24)
     err = (got - want).abs().max().item()
@@ -64,12 +64,11 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window, variant, m
 
 
 @pytest.mark.parametrize("occ", [21, 41, 42])  # (42 is not applicable beyond 16 tokens: the library falls back to 41)
-def test_more_than_sixteen_tokens_take_two_tiles(occ, monkeypatch):
+def test_more_than_sixteen_tokens_take_two_tiles(occ):
     """window 100 = 26 autoregressive calls, the last ones over 17..26 target tokens: two 16-token tiles in every product,
     keys beyond 16 in the attention; a feed-forward width that is not a multiple of 16 (zero-padded tile)."""
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
 
-    monkeypatch.setenv("DP_TEMPORAL_VARIANT", str(occ))
     torch.manual_seed(5)
     model = TemporalPredictor(n_encoder_layers=2, n_decoder_layers=2, dim_feedforward=200).eval()
     for p in model.parameters():
@@ -80,13 +79,15 @@ def test_more_than_sixteen_tokens_take_two_tiles(occ, monkeypatch):
     means, stds = 0.2 * torch.randn(24, generator=g), 0.5 + torch.rand(24, generator=g)
     lat, disp, hts = torch.randn(S, H, 24, generator=g), 0.02 * torch.randn(S, H, 3, generator=g), 1.0 + 0.3 * torch.randn(S, H, 6, generator=g)
     want = _torch_block(model, means, stds, lat, disp, hts, window)
-    got = NativeTemporal(model, means, stds, device="cuda:0").predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
+    nat = NativeTemporal(model, means, stds, device="cuda:0")
+    nat._force_variant(occ)
+    got = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
     err = (got - want).abs().max().item()
     print(f"window {window}, variant {occ}: max |native - nn.Transformer| = {err:.2e}")
     assert err <= 2e-5, err
 
 
-@pytest.mark.parametrize("name", ["seq6", "seq3"])
+@pytest.mark.parametrize("name", ["seq6", "seq3", "seq4"])
 def test_native_predictor_reproduces_the_reference_targets(golden_dir, name):
     """Closed loop over the reference-recorded sequences with the native predictor in the operator: the `z_tgt` it hands the
     kernel, frame by frame, against the one the REFERENCE's Temporal produced (and the resulting state as in

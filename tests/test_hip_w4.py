@@ -209,59 +209,27 @@ def test_launches_are_graph_capturable(opt, dev, golden_dir):
     assert torch.equal(pose_ret, want_pose)
 
 
-@pytest.mark.parametrize("B", [1024, 8192])
-def test_baseline_config_batches_against_the_c_oracle(opt, dev, golden_dir, B):
-    """BASELINE configs 2 and 3 (1024 frames on one GPU; 8192 frames = 8 shards of 1024): every frame against the C oracle, and -- for
-    the 8192 -- a sample against the REAL reference (tests/golden/full8192_probe.npz: every 16th frame plus every frame a kernel or
-    the oracle pair ever singled out, through DragPose.run in fp32 and fp64).  "Sensitive frame" is defined by the reference's own
-    pair wherever the reference was run on the frame; the C-oracle pair only fills in for frames it was not run on.
-    The library picks the kernel: dp_w4 for 1024 frames, dp_w16 for the 8192 in one launch."""
+def test_baseline_config2_batch_against_the_c_oracle(opt, dev, golden_dir):
+    """BASELINE config 2 (1024 frames on one GPU): every frame against the C oracle pair.  (Config 3's 8192 frames are held to the REAL
+    reference's run of the whole batch since round 5: tests/test_hip_configs_at_size.py::test_config3_whole_batch_against_the_reference.)"""
     from dragposer_amd.optimizer import to_device_batch
 
+    B = 1024
     b = R.synth_inputs(R.OracleModel(), B)
-    ref_flag, probed = np.zeros(B, bool), np.zeros(B, bool)
-    if B == 8192:
-        pr = R.load_golden(os.path.join(golden_dir, "full8192_probe.npz"))
-        fr, T6 = pr["frames"], [0, 3, 7, 13, 17, 21]
-        assert np.abs(b["tgt_pos"][fr][:, T6] - pr["tgt_pos6"]).max() < 1e-5
-        for k, src in (("tgt_pos", pr["tgt_pos6"]), ("tgt_rot", pr["tgt_rot6"])):  # the targets as the reference saw them (host matmul bits)
-            rows = b[k][fr]
-            rows[:, T6] = src
-            b[k][fr] = rows
-        import hashlib
-
-        h = hashlib.sha256()
-        for k in KEYS:
-            h.update(np.ascontiguousarray(b[k][fr]).tobytes())
-        assert h.hexdigest() == pr["meta"]["digest"], "the probe frames' inputs are not the ones the reference was run on"
-        probed[fr] = True
-        ref_flag[fr] = pr["ref32_vs_ref64_mm"] > 0.02
     o = _run(opt, to_device_batch(b, dev), n_iter=50)
-    assert opt.kernel_geometry()[0] == (16 if B == 1024 else 64)  # frames per workgroup: 4 waves of 4 / of 16 frames
+    assert opt.kernel_geometry()[0] == 16  # frames per workgroup: 4 waves of 4 frames (dp_w4)
     a = [b[k] for k in KEYS]
     r32 = AnalyticOracle(precision="f32").optimize(*a, 50)
     r64 = AnalyticOracle(precision="f64").optimize(*a, 50)
-    osens = _mm(r32["pos"], r64["pos"]).max(axis=1) > 0.02  # the C-oracle pair parts ways
-    sens = np.where(probed, ref_flag, osens)                 # ... consulted only where the reference itself was not run
+    sens = _mm(r32["pos"], r64["pos"]).max(axis=1) > 0.02  # the C-oracle pair parts ways
     err = np.minimum(_mm(o["pos"], r32["pos"]).max(axis=1), _mm(o["pos"], r64["pos"]).max(axis=1))  # (on such a frame either is right)
-    if B == 8192:  # where the reference ran: its fp32 run is the truth to be near (its fp64 run on the frames its pair flags)
-        e_ref = np.minimum(_mm(o["pos"][fr], pr["pos"]).max(axis=1), np.where(ref_flag[fr], _mm(o["pos"][fr], pr["pos_f64"]).max(axis=1), np.inf))
-        print(f"B=8192: {len(fr)} frames against the real reference: p99 {np.percentile(e_ref, 99):.4f} mm, above 0.05 mm: frames {fr[e_ref > 0.05].tolist()} "
-              f"({np.round(e_ref[e_ref > 0.05], 3).tolist()} mm); the reference's own pair parts ways on {fr[ref_flag[fr]].tolist()} "
-              f"({np.round(pr['ref32_vs_ref64_mm'][ref_flag[fr]], 3).tolist()} mm); the C-oracle pair on {np.nonzero(osens)[0].tolist()}")
-        err[fr] = e_ref
     bad = np.nonzero(err > 0.05)[0]
     ok, kink, tiny = explained(b, bad, 50, 0.02, flagged=np.nonzero(sens)[0])
-    better = o["loss"][bad].sum(1) <= r32["loss"][bad].sum(1)
     print(f"B={B}: flagged frames {np.nonzero(sens)[0].tolist()}; above 0.05 mm: {bad.tolist()} ({np.round(err[bad], 3).tolist()} mm, "
-          f"reference run exists: {probed[bad].tolist()}, smallest |pre-activation| {kink.tolist()}, smallest |dL/dz_k| {tiny.tolist()}, "
-          f"final loss not above the oracle's: {better.tolist()}); p99 {np.percentile(err, 99):.4f} mm, mean {err.mean():.5f} mm")
-    # every miss shows a mechanism (tests/sensitivity.py); at most 0.1 % of the frames; a few mm, unless the kernel's route ended
-    # LOWER than the oracle's (seen once in 8192 frames: 14.7 mm away, total loss 7 % lower, 4e-7 from a kink)
-    assert sens.sum() <= max(2, B // 1000) and len(bad) <= max(2, B // 1000) and ok.all(), (bad, kink, tiny)
-    assert all(e <= 5.0 or bt for e, bt in zip(err[bad], better)), (err[bad], better)
+          f"smallest |pre-activation| {kink.tolist()}, smallest |dL/dz_k| {tiny.tolist()}); p99 {np.percentile(err, 99):.4f} mm, mean {err.mean():.5f} mm")
+    assert sens.sum() <= 2 and len(bad) <= 2 and ok.all() and err.max() <= 5.0, (bad, kink, tiny)
     good = err <= 0.05
-    np.testing.assert_allclose(o["loss"][good & ~sens & ~osens], r32["loss"][good & ~sens & ~osens], rtol=2e-3, atol=1e-8)  # (the C oracle's fp32 losses: not where its own pair parts ways)
+    np.testing.assert_allclose(o["loss"][good & ~sens], r32["loss"][good & ~sens], rtol=2e-3, atol=1e-8)
     assert (o["iters"] == 50).all()
 
 

@@ -25,7 +25,7 @@ def test_full_size_architecture_matches_reference_parameter_count():
     assert n == 1282536, n  # "# parameters temporal: 1282536" is what the reference prints for its shipped hyper-parameters
 
 
-@pytest.mark.parametrize("name", ["seq6", "seq3"])
+@pytest.mark.parametrize("name", ["seq6", "seq3", "seq4"])
 def test_temporal_block_first_frame(golden_dir, name):
     from dragposer_amd.drag_pose import DragPose
 

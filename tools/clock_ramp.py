@@ -19,6 +19,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import synth_on_device  # noqa: E402
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _diaglib import use_env_library  # tools/_diaglib.py: DRAGPOSER_LIB names a diagnostic build
+
+use_env_library()
 from dragposer_amd.optimizer import LatentOptimizer  # noqa: E402
 
 NAMES = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")

@@ -6,6 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import ref_torch as R
 from oracle.analytic import AnalyticOracle
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _diaglib import use_env_library  # tools/_diaglib.py: DRAGPOSER_LIB names a diagnostic build
+
+use_env_library()
 from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
 
 dev = torch.device("cuda:0")

@@ -213,6 +213,8 @@ def main():
         "f1_clip3": (clip, "3_trackers_config.json", False, 1),
         "f1_clip6_t": (clip, "6_trackers_config.json", True, 1),   # window 0: a prediction every frame
         "f1_clip3_t": (clip, "3_trackers_config.json", True, 1),   # window 16
+        "f1_clip4": (clip, "4_trackers_config.json", False, 1),    # the reference's third shipped configuration (pelvis + head + hands,
+        "f1_clip4_t": (clip, "4_trackers_config.json", True, 1),   #   joint adjustment [0, 0] with weight 1, lambda 0.125, window 16)
         "f1_example": (full, "6_trackers_config.json", False, 8),
     }
     for name, (path, cfgname, ton, stride) in jobs.items():

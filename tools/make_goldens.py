@@ -387,29 +387,6 @@ def full_size_reference(name, B, seed, gold, offsets, parents, workers, trackers
           f"max {dj.max():.4f} mm; > 0.02 mm on {len(sens)} frames {sens.tolist()[:40]} ({np.round(d[sens], 3).tolist()[:40]} mm)")
 
 
-def probe_reference(name, B, seed, frames, gold, offsets, parents, workers, n_iter=50, lam_tmp=0.02):
-    """Chosen frames of a large recipe-S1 batch (BASELINE config 3: 8192 frames) through the REAL reference in fp32 and fp64: every
-    16th frame plus the frames a GPU kernel or the repo's C-oracle pair ever singled out (--probe-frames), so that "is this a frame
-    on which correct implementations part ways?" is answered by the reference itself, not by the repo's restatements."""
-    sys.path.insert(0, REPO)
-    from oracle import ref_torch as R  # inputs only
-
-    inp = R.synth_inputs(R.OracleModel(), B, seed=seed)
-    frames = np.array(sorted(set(int(f) for f in frames)), np.int32)
-    sub = {k: v[frames] for k, v in inp.items()}
-    o32 = run_frames_parallel(sub, n_iter, lam_tmp, offsets, parents, workers, dtype=torch.float32, progress=name + "_f32")
-    o64 = run_frames_parallel(sub, n_iter, lam_tmp, offsets, parents, workers, dtype=torch.float64, progress=name + "_f64")
-    d = (np.linalg.norm(o32["pos"] - o64["pos"], axis=-1).max(1) * 1000).astype(np.float32)
-    T6 = [0, 3, 7, 13, 17, 21]
-    meta = dict(name=name, B=B, seed=seed, n_iter=n_iter, lambda_tmp=lam_tmp, digest=inputs_digest(sub), torch=torch.__version__)
-    path = os.path.join(gold, f"{name}.npz")
-    np.savez_compressed(path, frames=frames, pos=o32["pos"], pos_f64=o64["pos"], z_final=o32["z_final"], loss_last=o32["loss_last"].astype(np.float32),
-                        tgt_pos6=sub["tgt_pos"][:, T6], tgt_rot6=sub["tgt_rot"][:, T6], ref32_vs_ref64_mm=d,
-                        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
-    print(f"wrote {path} {os.path.getsize(path)} bytes; {len(frames)} frames; reference fp32 vs fp64 > 0.02 mm on frames "
-          f"{frames[d > 0.02].tolist()} ({np.round(d[d > 0.02], 3).tolist()} mm)")
-
-
 def export_model(parents, offsets):
     sd = torch.load(os.path.join(REF, "models/model_dancedb/generator.pt"), map_location="cpu")["model_state_dict"]
     data = torch.load(os.path.join(REF, "models/model_dancedb/data.pt"), map_location="cpu")
@@ -580,8 +557,6 @@ def main():
     ap.add_argument("--only", default="model,anchors,s1,s3,s4,es,seq6,seq3,sequ,enc")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--workers", type=int, default=6)
-    ap.add_argument("--probe-frames", default="2392,4901,8124,2489,6005,6112,6516",
-                    help="full8192_probe: frames run through the reference besides every 16th (defaults: the frames dp_w16 / the C-oracle pair singled out in round 3)")
     args = ap.parse_args()
     todo = args.only.split(",")
     parents, offsets = parse_bvh_skeleton(os.path.join(REF, "data/example/eval/example.bvh"))
@@ -593,6 +568,8 @@ def main():
         cfg6 = json.load(f)
     with open(os.path.join(REF, "config/3_trackers_config.json")) as f:
         cfg3 = json.load(f)
+    with open(os.path.join(REF, "config/4_trackers_config.json")) as f:  # the reference's third shipped configuration: pelvis + head + hands
+        cfg4 = json.load(f)
     w6, w3 = torch.tensor(cfg6["weights"], dtype=torch.float32), torch.tensor(cfg3["weights"], dtype=torch.float32)
     B = args.frames
     if "model" in todo:
@@ -625,9 +602,6 @@ def main():
     if "full_s4_1024" in todo:  # BASELINE config 5 at size: 1-6 trackers per frame, bf16-rounded decoder weight tensors
         full_size_reference("full_s4_1024", 1024, 1234, gold, offsets, parents, args.workers, mixed=True, n_iter=50,
                             lam_tmp=cfg6["lambda_temporal"], weight_rounding="bf16", keep_f64=True)
-    if "full8192_probe" in todo:  # BASELINE config 3's 8192-frame batch: a reference-run sample + the frames ever singled out
-        extra = [int(f) for f in args.probe_frames.split(",") if f]
-        probe_reference("full8192_probe", 8192, 1234, list(range(0, 8192, 16)) + extra, gold, offsets, parents, args.workers)
     if "enc" in todo:
         path = os.path.join(gold, "enc.npz")
         np.savez_compressed(path, **encoder_golden(parents))
@@ -638,7 +612,8 @@ def main():
     # "sequ_switch": the same shape with the pull term switched on at frame 11 -- the fourth frame of the second window of 8: the
     # reference has been predicting at every window start all along (drag_pose.py:247-291 does not look at lambda_temporal)
     cfgs = dict(cfgu, lambda_switch_frame=11)
-    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78), ("sequ", cfgu, 1, 24, 79), ("sequ_switch", cfgs, 1, 24, 80)):
+    for name, cfg, K, T, seed in (("seq6", cfg6, 4, 24, 77), ("seq3", cfg3, 2, 36, 78), ("seq4", cfg4, 2, 36, 81), ("sequ", cfgu, 1, 24, 79),
+                                  ("sequ_switch", cfgs, 1, 24, 80)):
         if name in todo:
             out = run_sequences(name, K, T, cfg, offsets_t, parents, seed)
             path = os.path.join(gold, f"{name}.npz")

@@ -10,6 +10,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 import export_temporal_bin as X
 import test_unity_abi as U
 from oracle import ref_torch as R
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _diaglib import use_env_library  # tools/_diaglib.py: DRAGPOSER_LIB names a diagnostic build
+
+use_env_library()
 from dragposer_amd.temporal import TemporalPredictor
 
 tmp = tempfile.mkdtemp()

@@ -13,6 +13,11 @@ import argparse, json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _diaglib import use_env_library  # tools/_diaglib.py: DRAGPOSER_LIB names a diagnostic build
+
+use_env_library()
 from dragposer_amd import eval_drag as E
 from dragposer_amd.drag_pose import DragPose
 from dragposer_amd.encoder import PoseEncoder

@@ -4,6 +4,11 @@ Usage: tools/w16_early_stop_timing.py > gpurun_out/w16_early_stop.txt"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from oracle import ref_torch as R
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _diaglib import use_env_library  # tools/_diaglib.py: DRAGPOSER_LIB names a diagnostic build
+
+use_env_library()
 from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
 dev = torch.device("cuda:0")
 opt = LatentOptimizer(device=dev)

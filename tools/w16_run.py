@@ -5,6 +5,11 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import ref_torch as R
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _diaglib import use_env_library  # tools/_diaglib.py: DRAGPOSER_LIB names a diagnostic build
+
+use_env_library()
 from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
 
 kern, B = sys.argv[1], int(sys.argv[2])
