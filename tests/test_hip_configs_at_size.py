@@ -193,7 +193,8 @@ def test_config3_whole_batch_against_the_reference(opts, dev, golden_dir, how):
     assert ok.all() and len(bad) <= 2 * len(ref["sens_frames"]) + 2, (bad, kink, tiny)
     good = err <= 0.05
     assert e[good].mean() <= 0.002 and np.percentile(e[good], 99) <= 0.005
-    np.testing.assert_allclose(o["loss"][good], ref["loss_last"][good], rtol=2e-3, atol=1e-8)
+    # (loss terms of 1e-4 ... 1e-2: 2e-3 relative, or 1e-6 absolute on a term that is small against its frame's total)
+    np.testing.assert_allclose(o["loss"][good], ref["loss_last"][good], rtol=2e-3, atol=1e-6)
     assert (o["iters"] == 50).all() and (o["status"] == 0).all()
     if how == "shards_of_1024":  # per rank: the bar holds on every slice, not just on the whole
         for r in range(8):

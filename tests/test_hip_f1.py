@@ -78,11 +78,13 @@ def test_cli_against_the_reference_run_of_the_clip(golden_dir, tmp_path, name):
     same_t = g["twin_iters"] == g["iters"]
     print(f"{name}: the reference against ITSELF from a latent 1e-7 away: iteration counts equal on {same_t.mean():.3f} of the frames; joint positions max mm "
           + ", ".join(f"[{a},{b}) {dt[a:b].max():.4f}" for a, b in rng) + f"; MPJPE {float(g['twin_mpjpe']) * 1000:.3f} mm vs {float(g['mpjpe']) * 1000:.3f}")
-    assert same[:8].all() and d[:8].max() <= 0.05 and dg[:8].max() <= 0.05, (iters[:8], g["iters"][:8], d[:8].max())
+    six = len(np.nonzero(np.asarray(g["meta"]["cfg"]["mask"]))[0]) == 6
+    # (without the feet's trackers the legs hang on the shared latent: fp32 rounding shows in THEIR joint positions first -- 0.056 mm at frame 5 of
+    #  the 4-tracker clip with the pull term, iteration counts equal)
+    assert same[:8].all() and d[:8].max() <= (0.05 if six else 0.1) and dg[:8].max() <= 0.05, (iters[:8], g["iters"][:8], d[:8].max())
     assert same[:STRICT].all() and d[:STRICT].max() <= 0.2, (iters[:STRICT], g["iters"][:STRICT], d[:STRICT].max())
     # after the strict window: no farther from the reference than three times what the reference's own twin run is (per frame range;
     # a floor of 10 mm where the twin happened to stay together), sequence-level figures within 5 % or three times the twins' spread
-    six = len(np.nonzero(np.asarray(g["meta"]["cfg"]["mask"]))[0]) == 6
     spread = max(abs(float(g["twin_mpjpe"]) - float(g["mpjpe"])) / float(g["mpjpe"]), abs(float(g["twin_mpeepe"]) - float(g["mpeepe"])) / float(g["mpeepe"]))
     if six:
         for a, b in rng[1:]:
@@ -95,14 +97,16 @@ def test_cli_against_the_reference_run_of_the_clip(golden_dir, tmp_path, name):
         # is not a tracker at all), and stay together with it only as long as nothing perturbs them.  Held here: the first 32 frames
         # closely, the sequence-level figures loosely.
         assert d[:32].max() <= 1.0, d[:32].max()
-        np.testing.assert_allclose([res["mpjpe"], res["mpeepe"]], [float(g["mpjpe"]), float(g["mpeepe"])], rtol=max(0.25, 3.0 * spread))
+        # (the 4-tracker clip without the pull term, profiles/r05_clip_twins.txt: the product's OWN runs from initial latents 1e-7 ... 1e-4 apart
+        #  give MPEEPE 50 ... 71 mm at 1.7 ... 3.5 iterations per frame, the reference and its twin 80 / 73 mm at 4.1 / 3.3: a chaotic loop, one regime)
+        np.testing.assert_allclose([res["mpjpe"], res["mpeepe"]], [float(g["mpjpe"]), float(g["mpeepe"])], rtol=max(0.35, 3.0 * spread))
     assert abs(iters.mean() - g["iters"].mean()) <= max(0.1, 3.0 * abs(g["twin_iters"].mean() - g["iters"].mean()) / g["iters"].mean()) * g["iters"].mean() + 1.5
     assert same.mean() >= 0.5 * same_t.mean()
     # the written file: on the strict window, the reference's MOTION block
     mine = BVH().load(res["out"]).motion
     dm = np.abs(mine[:STRICT] - g["result_motion_all"][:STRICT])
     dm[:, 3:] = np.minimum(dm[:, 3:], np.abs(dm[:, 3:] - 360.0))
-    assert dm[:8].max() <= 5e-3 and dm.max() <= 5e-2, (dm[:8].max(), dm.max())  # degrees / metres as printed (6 decimals)
+    assert dm[:8].max() <= (5e-3 if six else 1e-2) and dm.max() <= 5e-2, (dm[:8].max(), dm.max())  # degrees / metres as printed (6 decimals)
 
 
 def test_cli_on_the_whole_example_file_against_the_reference_run(golden_dir, tmp_path):
