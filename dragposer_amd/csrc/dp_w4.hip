@@ -144,20 +144,25 @@ DEV void chain_end(f4& acc0, f4& acc1) { asm volatile("s_nop 2" : "+v"(acc0), "+
 
 // NG groups from resident weights (accumulator registers) / from weights in vector registers
 // START: 0 continues a chain; 1 starts one from the bias row `bias`; 2 starts one from zero
-template <int NG, int ABID0, int START = 0> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv, const f4& bias = f4{0.f, 0.f, 0.f, 0.f})
+// SKIP: bit (ABID0 + g) set = group g is left out (bL2: the K-steps of an item whose dL/dy is zero in all four frames of the wave, below)
+template <int NG, int ABID0, int START = 0, unsigned SKIP = 0u> DEV void chain_a(f4& acc0, f4& acc1, const f4& x, const f4* wv, const f4& bias = f4{0.f, 0.f, 0.f, 0.f})
 {
+    static_assert(START == 0 || !(SKIP & (1u << ABID0)), "the group that starts a chain is not skipped");
     static_for<NG>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
-        if constexpr (g == 0 && START == 1) first_a_biased<ABID0>(acc0, acc1, x, wv[0], bias);
+        if constexpr ((SKIP >> (ABID0 + g)) & 1u) {}
+        else if constexpr (g == 0 && START == 1) first_a_biased<ABID0>(acc0, acc1, x, wv[0], bias);
         else if constexpr (g == 0 && START == 2) first_a_zero<ABID0>(acc0, acc1, x, wv[0]);
         else group_a<ABID0 + g>(acc0, acc1, x, wv[g]);
     });
 }
-template <int NG, int ABID0, int START = 0> DEV void chain_v(f4& acc0, f4& acc1, const f4& x, const f4* wv)
+template <int NG, int ABID0, int START = 0, unsigned SKIP = 0u> DEV void chain_v(f4& acc0, f4& acc1, const f4& x, const f4* wv)
 {
+    static_assert(START == 0 || !(SKIP & (1u << ABID0)), "the group that starts a chain is not skipped");
     static_for<NG>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
-        if constexpr (g == 0 && START == 2) first_v_zero<ABID0>(acc0, acc1, x, wv[0]);
+        if constexpr ((SKIP >> (ABID0 + g)) & 1u) {}
+        else if constexpr (g == 0 && START == 2) first_v_zero<ABID0>(acc0, acc1, x, wv[0]);
         else group_v<ABID0 + g>(acc0, acc1, x, wv[g]);
     });
 }
@@ -178,9 +183,12 @@ DEV f4 add_halves(f4 v)
     }
     return v;
 }
-template <int NG> DEV void load_w(f4* wv, const f4* w)
-{
-    static_for<NG>([&](auto gi) { constexpr int g = decltype(gi)::value; wv[g] = w[g * 64]; });
+template <int NG, int ABID0 = 0, unsigned SKIP = 0u> DEV void load_w(f4* wv, const f4* w)
+{ // (SKIP as in chain_a / chain_v: the weights of a group that is left out are not read)
+    static_for<NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (!((SKIP >> (ABID0 + g)) & 1u)) wv[g] = w[g * 64];
+    });
 }
 
 // an empty asm that "uses" NG weight groups (accumulator / vector registers): pins where the wait for their loads stands
@@ -969,6 +977,22 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             m &= m - 1u;
         }
     }
+    // bL2's dead K-groups (see `bl2` in the loop): side-A item b is live when its joint, or a joint below its child bone, is tracked in one of
+    // the wave's four frames.  Two skip patterns are compiled: items 4 and 8 (mode 1), items 1..8 (mode 2); a mode is taken only when every item
+    // of its pattern is dead -- whatever the skeleton and the tracker sets are, a skipped group multiplies zeros.
+    constexpr unsigned B2_SKIP_1 = (1u << 4) | (1u << 8), B2_SKIP_2 = 0x1FEu;
+    int b2_mode = 0;
+    {
+        const unsigned tm_any = (unsigned)__builtin_amdgcn_readlane((int)tmask, 0) | (unsigned)__builtin_amdgcn_readlane((int)tmask, 1) |
+                                (unsigned)__builtin_amdgcn_readlane((int)tmask, 2) | (unsigned)__builtin_amdgcn_readlane((int)tmask, 3);
+        const bool liveA = kindA != KIND_JOINT || ((pc.subA | (1u << pc.itemA)) & tm_any) != 0u; // (the root always is)
+        const unsigned long long lv = __ballot(liveA);
+        unsigned live16 = 0; // bit b: side-A item of quad b
+#pragma unroll
+        for (int q = 0; q < 16; ++q) live16 |= (unsigned)((lv >> (4 * q)) & 1ull) << q;
+        b2_mode = (live16 & B2_SKIP_2) == 0u ? 2 : (live16 & B2_SKIP_1) == 0u ? 1 : 0;
+        if (!optimise) b2_mode = 0;
+    }
     TRec trk;
     {
         const Q4 cur = {cv.x, cv.y, cv.z, cv.w};
@@ -1151,7 +1175,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         // pinned: the scheduler would move the reads next to their use)
         constexpr int NQ = 8 - B2_RES;
         f4 wq[NQ], wr[8], ws[10];
-        load_w<NQ>(wq, w2 + B2_RES * 64);
+        // (uniform; mode 2 leaves groups 1..8 out, see bl2 below: its chain goes from group 0 straight to group 9, so groups 9.. take the
+        //  first chunk's registers and its place here -- requested at the head of the chain they would come back an LDS round trip late)
+        if (EARLY || b2_mode != 2) load_w<NQ>(wq, w2 + B2_RES * 64);
+        else load_w<NQ>(wq, w2 + 9 * 64);
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
         STAMP(4);
@@ -1201,17 +1228,48 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 
         // ================= bL2: d1 = (A2^T gy) * lrelu'(a1): K = 4 channels of the 16 side-A items (gyA), then of side-B
         // quads 1..10 (gyB)
-        load_w<8>(wr, w2 + 8 * 64);
-        __builtin_amdgcn_sched_barrier(0);
-        chain_begin();
-        chain_a<B2_RES_A, 0, 2>(acc0, acc1, gyA, wB2a);
-        chain_v<B2_RES_V, B2_RES_A>(acc0, acc1, gyA, wB2v);
-        chain_v<NQ, B2_RES>(acc0, acc1, gyA, wq);
-        load_w<10>(ws, w2 + 16 * 64); // (into the registers the first chunk has just released)
-        __builtin_amdgcn_sched_barrier(0);
-        chain_v<8, 8>(acc0, acc1, gyA, wr);
-        chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
-        chain_end(acc0, acc1);
+        // A side-A item (= joint) whose dL/dy is exactly zero in all four frames of the wave -- neither it nor anything below its child bone
+        // carries a tracker (the toes under the reference's 6 trackers; both legs under its 3- and 4-tracker sets) -- adds
+        // nothing in its four K-steps: they are left out, with the read of their weights.  Which items is decided per wave in the set-up
+        // (b2_mode); two patterns are compiled beside the general one, selected by a uniform branch per iteration.
+        const auto bl2 = [&](auto skip_tag) {
+            constexpr unsigned SK = decltype(skip_tag)::value;
+            if constexpr (SK == B2_SKIP_2) { // group 0 | 9 .. 9 + NQ - 1 (in wq's registers, requested ahead of stage G) | the rest of side A | side B
+                static_assert(NQ >= 1 && NQ <= 6, "mode 2 keeps groups 9.. in the first chunk's registers");
+                load_w<7 - NQ>(wr, w2 + (9 + NQ) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                chain_begin();
+                chain_a<B2_RES_A, 0, 2, SK>(acc0, acc1, gyA, wB2a);
+                chain_v<NQ, 9>(acc0, acc1, gyA, wq);
+                load_w<10>(ws, w2 + 16 * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                chain_v<7 - NQ, 9 + NQ>(acc0, acc1, gyA, wr);
+            } else {
+                load_w<8, 8, SK>(wr, w2 + 8 * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                chain_begin();
+                chain_a<B2_RES_A, 0, 2, SK>(acc0, acc1, gyA, wB2a);
+                chain_v<B2_RES_V, B2_RES_A, 0, SK>(acc0, acc1, gyA, wB2v);
+                chain_v<NQ, B2_RES, 0, SK>(acc0, acc1, gyA, wq);
+                load_w<10>(ws, w2 + 16 * 64); // (into the registers the first chunk has just released)
+                __builtin_amdgcn_sched_barrier(0);
+                chain_v<8, 8, 0, SK>(acc0, acc1, gyA, wr);
+            }
+            chain_v<B2_GROUPS_B, B2_ABID0_B>(acc0, acc1, gyB, ws);
+            chain_end(acc0, acc1);
+        };
+        // (the early-stop and whole-sequence instantiations keep the one general chain: with their larger live state the three-way branch
+        //  costs them spills inside the loop -- 3 and 39 registers, measured at compile time)
+#ifdef W4_NO_B2_SKIP
+        bl2(std::integral_constant<unsigned, 0u>{});
+#else
+        if constexpr (EARLY) bl2(std::integral_constant<unsigned, 0u>{});
+        else {
+            if (b2_mode == 0) bl2(std::integral_constant<unsigned, 0u>{});
+            else if (b2_mode == 1) bl2(std::integral_constant<unsigned, B2_SKIP_1>{});
+            else bl2(std::integral_constant<unsigned, B2_SKIP_2>{});
+        }
+#endif
         x = (acc0 + acc1) * f1D;
         QT(x);
         STAMP(6);

@@ -105,4 +105,5 @@ def test_hand_written_mfma_groups_keep_their_wait_states():
     import check_mfma_hazards as H
 
     n_mfma, counts, bad = H.check(H.isa([]))
-    assert n_mfma == 3 * 396 and counts["C"] > 1000 and counts["AB"] >= 15 and counts["R"] >= 30 and not bad, (n_mfma, counts, bad[:5])
+    # 396 per instantiation + the fixed-count kernel's two extra copies of the bL2 chain with its dead K-groups left out (96 and 72 of 104 MFMAs)
+    assert n_mfma == 3 * 396 + 96 + 72 and counts["C"] > 1000 and counts["AB"] >= 15 and counts["R"] >= 30 and not bad, (n_mfma, counts, bad[:5])
