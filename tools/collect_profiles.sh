@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r04/).
+# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r05/).
 # rocprofv3: program directly after `--`; counters in their own passes with --kernel-trace only.
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/prof_r04
+O=gpurun_out/prof_r05
 rm -rf $O && mkdir -p $O
 # 1. kernel-trace stats of the default bench command
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --no-cpu-baseline --traffic file > $O/bench_under_rocprof.json 2> $O/stats.log
@@ -63,10 +63,11 @@ python3 bench.py > $O/bench_default.json 2> /dev/null
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 python3 -m pytest tests -q -m gpu -s 2>&1 | grep -v "amdgpu.ids\|Warning\|warnings.warn\|self.encoder" > $O/gpu_tests_log.txt || true
 echo "bench + tests done"
-# 11. round 4: the cooperative-shape probe, where the at-size misses start, the closed loop's sensitivity
-tools/ubench/bin/coop_probe 256 58 > $O/coop_probe.txt 2>&1 || true
-python3 tools/frame_divergence.py full_s4_1024 w16 962,502 2>&1 | grep -v amdgpu.ids > $O/divergence_s4.txt || true
-python3 tools/frame_divergence.py full_s3_1024 w16 316,651,746,870 2>&1 | grep -v amdgpu.ids > $O/divergence_s3.txt || true
-python3 tools/temporal_divergence.py 2>&1 | grep -v "amdgpu.ids\|Warning\|self.encoder\|^Frame:" > $O/temporal_divergence.txt || true
-echo "round-4 probes done"
+# 11. round 5: the clock ramp (DVFS), the part-by-part ablation of dp_w4 at the steady clock (libraries built by tools/ablate_w4.sh on the build
+#     host before this call), the dead-K-group A/B on the reference's three tracker configurations, the product's own closed-loop spread
+python3 tools/clock_ramp.py 2>&1 | grep -v amdgpu.ids > $O/clock_ramp.txt || true
+if ls _scratch/lib_ab_*.so > /dev/null 2>&1; then LIBS="$(ls _scratch/lib_ab_*.so | tr '\n' ' ')" REPS=3 bash tools/ab.sh > $O/ablation.txt 2>&1 || true; fi
+if [ -f _scratch/lib_noskip.so ]; then REPS=3 python3 tools/ab_configs.py _scratch/lib_noskip.so dragposer_amd/lib/libdragposer_hip.so > $O/b2_skip_ab.txt 2>&1 || true; fi
+python3 tools/clip_twins.py f1_clip4 f1_clip4_t 2>/dev/null | grep -v "^Mean\|^Time\|^Evaluate\|^Frames" > $O/clip_twins.txt || true
+echo "round-5 probes done"
 ls $O
