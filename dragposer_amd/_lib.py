@@ -17,7 +17,7 @@ DP_ERR_UNSUPPORTED = -3
 DP_ERR_LAUNCH = -4
 DP_WEIGHTS_FP32 = 0
 DP_WEIGHTS_BF16 = 1
-DP_MAX_ITERS = 256
+DP_MAX_ITERS = 1000000
 DP_KERNEL_AUTO, DP_KERNEL_W4, DP_KERNEL_W16 = 0, 1, 2
 
 _f = C.POINTER(C.c_float)

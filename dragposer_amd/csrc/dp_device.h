@@ -61,6 +61,17 @@ DEV void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Adam's two per-iteration scalars beyond the kernel-argument table (iteration index >= MAX_ITERS; dp_kernel.h: AdamCont).  `st`: this wave's two
+// running products in LDS (every lane reads, computes and writes the same values: nothing is held in registers from one iteration to the next).
+DEV void adam_beyond(double* st, const AdamCont& c, float& step, float& rbc2s)
+{
+    const double b1 = st[0] * c.beta1, b2 = st[1] * c.beta2;
+    st[0] = b1;
+    st[1] = b2;
+    step = (float)(c.lr / (1.0 - b1));
+    rbc2s = (float)(1.0 / sqrt(1.0 - b2));
+}
+
 DEV float lrelu(float x) { return fmaxf(x, 0.2f * x); }
 DEV float dlrelu(float a, float g) { return a > 0.f ? g : 0.2f * g; } // torch: x > 0 ? g : g*slope
 

@@ -617,6 +617,23 @@ static int take_result(dp_ctx* ctx, const dp_result* r, dp_result& o, const char
     return DP_OK;
 }
 
+// Adam's per-iteration scalars, as torch computes them in Python doubles: a table for the first MAX_ITERS iterations (in the kernel arguments), and
+// what the kernels need to continue the two products on the device beyond it (dp_kernel.h: AdamCont)
+static void fill_adam(KArgs& k, const dp_params& p)
+{
+    double b1t = 1.0, b2t = 1.0;
+    for (int t = 0; t < MAX_ITERS; ++t) {
+        b1t *= (double)p.beta1;
+        b2t *= (double)p.beta2;
+        if (t < p.n_iter) {
+            k.tab.step[t] = (float)((double)p.lr / (1.0 - b1t));
+            k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
+        }
+    }
+    k.cont.beta1 = (double)p.beta1; k.cont.beta2 = (double)p.beta2; k.cont.lr = (double)p.lr;
+    k.cont.b1t = b1t; k.cont.b2t = b2t;
+}
+
 static void fill_results(const dp_result* out, KArgs& k)
 {
     if (!out) return;
@@ -660,7 +677,11 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
     if (in->n_frames <= 0) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_frames must be positive");
     if (!in->z0 || !in->z_tgt || !in->cur_rot || !in->tgt_pos || !in->tgt_rot || !in->w || !in->tracked)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL input array");
-    if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1,256]");
+#ifdef DP_REF8_BUILD
+    if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1,256] (the test-only kernel reads the argument table only)");
+#else
+    if (p->n_iter < 1 || p->n_iter > DP_MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1, DP_MAX_ITERS]");
+#endif
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: bad Adam hyper-parameters");
     if (!(p->eps > 0.f)) return fail(ctx, DP_ERR_INVALID, "dp_optimize: Adam eps must be > 0 (include/dragposer.h: dp_params.eps)");
@@ -677,20 +698,17 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
     k.eps = p->eps;
     k.early_stop = p->early_stop ? 1 : 0;
     k.stop_eps_pos = p->stop_eps_pos; k.stop_eps_rot = p->stop_eps_rot; k.min_loss_incr = p->min_loss_incr;
-    double b1t = 1.0, b2t = 1.0;
-    for (int t = 0; t < p->n_iter; ++t) {
-        b1t *= (double)p->beta1;
-        b2t *= (double)p->beta2;
-        k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
-        k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
-    }
+    fill_adam(k, *p);
     // which kernel (include/dragposer.h: DP_KERNEL_*)
     const bool w16_can = ctx->d_w16img != nullptr;
     if (p->kernel != DP_KERNEL_AUTO && p->kernel != DP_KERNEL_W4 && p->kernel != DP_KERNEL_W16)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: unknown kernel selector");
     if (p->kernel == DP_KERNEL_W16 && !w16_can)
         return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 is laid out for the reference's 22-joint skeleton only");
-    const int kernel = p->kernel == DP_KERNEL_AUTO ? dp_auto_kernel(ctx, in->n_frames) : p->kernel;
+    // beyond the argument table of Adam scalars (n_iter > 256) only dp_w4 has instantiations that continue them on the device (dp_w4.hip: LONG)
+    if (p->kernel == DP_KERNEL_W16 && p->n_iter > MAX_ITERS)
+        return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 takes n_iter <= 256 (more iterations: DP_KERNEL_AUTO or DP_KERNEL_W4)");
+    const int kernel = p->kernel == DP_KERNEL_AUTO ? (p->n_iter > MAX_ITERS ? DP_KERNEL_W4 : dp_auto_kernel(ctx, in->n_frames)) : p->kernel;
     return launch(ctx, k, stream, kernel);
 }
 
@@ -760,7 +778,7 @@ extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const
         if (st->height_joints[h] < 0 || st->height_joints[h] >= NJ) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad height joint");
     if (adj && (adj->adjust_joint >= NJ || (adj->adjust_joint >= 0 && (adj->adjust_target_joint < 0 || adj->adjust_target_joint >= NJ))))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad joint adjustment");
-    if (p->n_iter < 1 || p->n_iter > MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: n_iter out of range [1,256]");
+    if (p->n_iter < 1 || p->n_iter > DP_MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: n_iter out of range [1, DP_MAX_ITERS]");
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: bad Adam hyper-parameters");
     if (!(p->eps > 0.f)) return fail(ctx, DP_ERR_INVALID, "dp_optimize_sequence: Adam eps must be > 0 (include/dragposer.h: dp_params.eps)");
@@ -774,13 +792,7 @@ extern "C" int dp_optimize_sequence(dp_ctx* ctx, int n_seq, float* latent, const
     k.eps = p->eps;
     k.early_stop = 1;
     k.stop_eps_pos = p->stop_eps_pos; k.stop_eps_rot = p->stop_eps_rot; k.min_loss_incr = p->min_loss_incr;
-    double b1t = 1.0, b2t = 1.0;
-    for (int t = 0; t < p->n_iter; ++t) {
-        b1t *= (double)p->beta1;
-        b2t *= (double)p->beta2;
-        k.tab.step[t] = (float)((double)p->lr / (1.0 - b1t));
-        k.tab.bc2s[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
-    }
+    fill_adam(k, *p);
     SeqK& q = k.seq;
     q.n_steps = fr->n_steps; q.z_tgt_step = fr->z_tgt_step; q.z_tgt_seq = fr->z_tgt_seq; q.tgt_root = fr->tgt_root;
     q.global_pos = st->global_pos; q.global_rot = st->global_rot; q.hist = out->hist_scratch; q.pos_ret = out->pos_ret;

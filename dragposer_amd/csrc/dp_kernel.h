@@ -10,6 +10,13 @@ struct AdamTab { // per-iteration scalars torch's single-tensor Adam computes in
     float step[dpl::MAX_ITERS]; // lr / (1 - beta1^t)
     float bc2s[dpl::MAX_ITERS]; // 1 / sqrt(1 - beta2^t)
 };
+// ... for the first MAX_ITERS iterations (the table rides in the kernel arguments: 2 KB of their 4).  A frame that iterates longer -- the reference
+// has no cap on max_iter -- continues the two products in double on the device (adam_beyond, dp_device.h), one uniform f64 sequence per iteration
+// beyond the table: what the host would have computed, at ~10 % more per such iteration.
+struct AdamCont {
+    double beta1, beta2, lr;
+    double b1t, b2t; // beta1^MAX_ITERS, beta2^MAX_ITERS
+};
 
 // debug dump (iteration 0 only), floats per frame
 constexpr int DBG_Y = 0;     // [104] decoder output quads (sum of the two K-half planes)
@@ -59,6 +66,7 @@ struct KArgs {
     SeqK seq;
     unsigned smask[dpl::NWAVE][dpl::NGEMM]; // bit i: step i of the wave's chain has a non-zero weight block
     AdamTab tab;
+    AdamCont cont;
 };
 
 extern "C" hipError_t dp_launch_optimize(const KArgs* args, hipStream_t stream);

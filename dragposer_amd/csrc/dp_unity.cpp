@@ -399,7 +399,7 @@ void drag_pose(DragPoser* d, int nEE, dp_float3* tp, dp_quaternion* tq, dp_quate
     d->err.clear();
     if (!d->ctx || !d->initialised) { d->fail("drag_pose: call load_models and init_drag_model first"); return; }
     if (nEE != (int)d->mask_idx.size()) { d->fail("drag_pose: nEndEffectors differs from the tracker mask"); return; }
-    if (d->max_iter < 1 || d->max_iter > DP_MAX_ITERS) { // (the reference has no cap; the kernel's per-iteration Adam table has)
+    if (d->max_iter < 1 || d->max_iter > DP_MAX_ITERS) { // (the reference has no cap; DP_MAX_ITERS is a sanity bound)
         d->fail("drag_pose: maxIter must be in [1, " + std::to_string(DP_MAX_ITERS) + "]");
         return;
     }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     // ---- set-up: the weight image, bias rows and the Adam table into LDS (once per workgroup)
     for (int k = tid; k < IMG_U32 / 4; k += NW * 64) ((u4*)(lds + L16_IMG))[k] = ((const u4*)a.w16img)[k];
     for (int k = tid; k < BIAS_FLOATS; k += NW * 64) ((float*)lds)[L16_BIAS + k] = a.w16bias[k];
-    for (int k = tid; k < a.n_iter; k += NW * 64) *(f2*)((float*)lds + L16_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]};
+    for (int k = tid; k < a.n_iter; k += NW * 64) *(f2*)((float*)lds + L16_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]}; // (n_iter <= MAX_ITERS: dp_host.cpp)
 
     // latent and Adam state in the D layout: tile n, register r = latent dim 16 n + 4 g + r (dims 24..31: zero, stay zero)
     f4 z[2], zt[2], mA[2], vA[2];

@@ -68,7 +68,10 @@ constexpr int L_OC = L_TAB + 2 * MAX_ITERS;     // [16 quads][20] what the epilo
 constexpr int L_ARGS = L_OC + 16 * 20;          // whole-sequence launches: the fields of the argument block a step reads (StepArgs)
 constexpr int L_ARGS_WORDS = 80;
 constexpr int L_FR = L_ARGS + L_ARGS_WORDS;     // frame blocks [NW * 4][FB_STRIDE]
-template <int NW> constexpr int lds_total() { return L_FR + NW * FPW * FB_STRIDE; }
+// ... and behind them (so that nothing else moves: shifting the frame blocks by 32 words cost the headline 1 %) [NW waves][2 doubles]: Adam's
+// running products beyond the argument table (adam_beyond; LONG instantiations only)
+template <int NW> constexpr int lds_adx() { return (L_FR + NW * FPW * FB_STRIDE + 1) & ~1; }
+template <int NW> constexpr int lds_total() { return lds_adx<NW>() + NW * 4; }
 
 // ------------------------------------------------------------------------------------------------
 // One group = four K-steps on two accumulators: step m multiplies x[m] (channel 4 ABID + m of the X-layout operand, block
@@ -768,7 +771,10 @@ DEV void w4_outputs(const A& a, const OutC& oc, float* fb, int gf, bool optimise
 // SEQ (whole-sequence launches, dp_optimize_sequence): frames are SEQUENCES; the kernel loops over a.seq.n_steps frame indices,
 // carrying every sequence's state (latent, global position / rotation) from step to step in registers and LDS -- the per-frame
 // epilogue of drag_pose.py:369-402 included -- and writes each step's results to the step's slab of the output arrays.
-template <int NW, bool EARLY, bool SEQ = false>
+// LONG: n_iter beyond the kernel-argument table of Adam scalars (MAX_ITERS: the reference has no cap on max_iter) -- the same kernel with one
+// uniform branch per iteration that continues the two bias corrections in double (adam_beyond).  Its own instantiations, because that branch,
+// never taken, costs the ordinary launches 1.5-3 % (measured: it perturbs the loop's schedule); they are what every launch with n_iter <= 256 runs.
+template <int NW, bool EARLY, bool SEQ = false, bool LONG = false>
 __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 {
     static_assert(!SEQ || EARLY, "sequences run the reference's while-condition");
@@ -858,7 +864,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         const ItemConst* ib = a.items + max(item_of(1, b), 0);
         ocv[4] = f4{__uint_as_float(ia->path_lo), __uint_as_float(ia->path_hi), __uint_as_float(ib->path_lo), __uint_as_float(ib->path_hi)};
     }
-    const f2 adam_row = tid < a.n_iter ? f2{a.tab.step[tid], a.tab.bc2s[tid]} : f2{0.f, 0.f}; // (n_iter <= 256 = one row per thread)
+    const f2 adam_row = tid < min(a.n_iter, MAX_ITERS) ? f2{a.tab.step[tid], a.tab.bc2s[tid]} : f2{0.f, 0.f}; // (one row of the table per thread)
     __builtin_amdgcn_sched_barrier(0);
 
     // the image into LDS (the small loads above stay in flight: loads return in issue order and the image came first)
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         *(f4*)(fb0 + fr * FB_STRIDE + (r < NW_LP ? FB_WT + 4 * r : r < NW_LP + 2 * W4_R ? FB_GP + 4 * (r - NW_LP) : FB_BN + 4 * SLOT_ZERO)) = f4{0.f, 0.f, 0.f, 0.f};
     }
     static_assert(MAX_ITERS <= NW * 64, "one row of the Adam table per thread");
-    if (tid < a.n_iter) *(f2*)(lds + L_TAB + 2 * tid) = adam_row;
+    if (tid < min(a.n_iter, MAX_ITERS)) *(f2*)(lds + L_TAB + 2 * tid) = adam_row;
     if (oc_lane) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) *(f4*)(lds + L_OC + 20 * b + 4 * k) = ocv[k];
@@ -1055,7 +1061,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #else
 #define SQ_STAMP(i)
 #endif
+    double* adx = (double*)(lds + lds_adx<NW>()) + 2 * wave;
     do { // (one pass unless SEQ)
+    if (LONG) { adx[0] = a.cont.b1t; adx[1] = a.cont.b2t; } // (every frame / step starts Adam afresh, drag_pose.py:218)
     if (SEQ) {
         const auto& as = step_args_of<SEQ>(a, lds);
         V3 step_shift = {0.f, 0.f, 0.f};
@@ -1117,8 +1125,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     SQ_STAMP(0);
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = (iter == a.n_iter - 1);
-        const f2 adam_t = *(const f2*)(lds + L_TAB + 2 * iter); // (an LDS broadcast read, issued a whole iteration ahead of its use)
-        const float step = adam_t.x, rbc2s = adam_t.y;
+        const f2 adam_t = *(const f2*)(lds + L_TAB + 2 * (LONG ? min(iter, MAX_ITERS - 1) : iter)); // (an LDS broadcast read, issued a whole iteration ahead of its use)
+        float step = adam_t.x, rbc2s = adam_t.y;
+        if constexpr (LONG) {
+            if (iter >= MAX_ITERS) adam_beyond(adx, a.cont, step, rbc2s); // (uniform: beyond the argument table)
+        }
         int o = lane;
         asm volatile("" : "+v"(o)); // opaque per iteration: keeps the streamed weight reads inside the loop
         const f4* w2 = (const f4*)(lds + L_IMG2) + o;
@@ -1457,12 +1468,17 @@ extern "C" hipError_t dp_launch_w4(const KArgs* args, hipStream_t stream)
 {
     constexpr int NW = 4;
     const int grid = (args->n_frames + NW * FPW - 1) / (NW * FPW);
-    if (args->seq.n_steps > 0)
-        hipLaunchKernelGGL((dp_w4_kernel<NW, true, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
-    else if (args->early_stop && args->mode == 0)
-        hipLaunchKernelGGL((dp_w4_kernel<NW, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
-    else
-        hipLaunchKernelGGL((dp_w4_kernel<NW, false>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    const bool lng = args->n_iter > MAX_ITERS;
+    if (args->seq.n_steps > 0) {
+        if (lng) hipLaunchKernelGGL((dp_w4_kernel<NW, true, true, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+        else hipLaunchKernelGGL((dp_w4_kernel<NW, true, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    } else if (args->early_stop && args->mode == 0) {
+        if (lng) hipLaunchKernelGGL((dp_w4_kernel<NW, true, false, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+        else hipLaunchKernelGGL((dp_w4_kernel<NW, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    } else {
+        if (lng) hipLaunchKernelGGL((dp_w4_kernel<NW, false, false, true>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+        else hipLaunchKernelGGL((dp_w4_kernel<NW, false>), dim3(grid), dim3(NW * 64), 0, stream, *args);
+    }
     return hipGetLastError();
 }
 

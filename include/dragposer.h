@@ -54,7 +54,9 @@ extern "C" {
 #define DP_NUM_JOINTS 22
 #define DP_LATENT 24
 #define DP_POSE_CHANNELS 88 /* 22 joints x 4 quaternion channels */
-#define DP_MAX_ITERS 256
+#define DP_MAX_ITERS 1000000 /* a sanity bound, not a table size: the reference has no cap on max_iter.  Adam's per-iteration scalars come from a
+                                256-entry table in the kernel arguments; a frame that iterates longer continues them in double on the device (0.5.0;
+                                earlier versions refused n_iter > 256) */
 
 typedef enum dp_status {
     DP_OK = 0,
@@ -122,7 +124,7 @@ typedef struct dp_params {
     unsigned struct_size; /* sizeof(dp_params) in the caller's translation unit (DP_PARAMS_INIT sets it).  The library refuses a
                              value below the 0.5.0 size (a 0.4 caller's first word is n_iter <= 256: always refused) and reads no
                              field beyond it */
-    int n_iter;        /* max_iter; exactly n_iter iterations when early_stop == 0 (<= DP_MAX_ITERS) */
+    int n_iter;        /* max_iter; exactly n_iter iterations when early_stop == 0 (1 .. DP_MAX_ITERS) */
     float lr;          /* learning_rate */
     float beta1, beta2, eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8.  eps must be > 0 (DP_ERR_INVALID otherwise): torch accepts 0,
                                 where a gradient component that is exactly 0 gives 0/0 = NaN; the kernels also carry the latent's
@@ -143,6 +145,7 @@ typedef struct dp_params {
  *                  exact sum of three bf16 terms, six term products per block accumulated in fp32), fixed iteration count or
  *                  early stop; the reference's 22-joint skeleton only (DP_ERR_UNSUPPORTED otherwise).  Pays as soon as W4 needs a
  *                  second round (it holds 16 frames per CU at a time: 4096 on an MI355X).
+ *                  n_iter <= 256 (the kernel-argument table of Adam scalars; beyond it: DP_ERR_UNSUPPORTED, DP_KERNEL_AUTO takes W4 then).
  *   DP_KERNEL_AUTO W16 for more than 16 frames per CU (> 4096 on an MI355X), either weight type, with or without early stop (both
  *                  kernels compute in fp32-equivalent arithmetic and are held to the same reference runs,
  *                  tests/test_hip_parity.py::test_full_size_batch_properties, tests/test_hip_w16.py); W4 otherwise -- BASELINE's

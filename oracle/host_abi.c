@@ -114,7 +114,7 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_re
     if (in->n_frames <= 0) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_frames must be positive");
     if (!in->z0 || !in->z_tgt || !in->cur_rot || !in->tgt_pos || !in->tgt_rot || !in->w || !in->tracked)
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL input array");
-    if (p->n_iter < 1 || p->n_iter > DP_MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1,256]");
+    if (p->n_iter < 1 || p->n_iter > DP_MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1, DP_MAX_ITERS]");
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: bad Adam hyper-parameters");
     if (!(p->eps > 0.f)) return fail(ctx, DP_ERR_INVALID, "dp_optimize: Adam eps must be > 0 (include/dragposer.h: dp_params.eps)");

@@ -296,7 +296,7 @@ def test_argument_validation(opt, dev, golden_dir):
     g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
     d = to_device_batch(g, dev)
     with pytest.raises(_lib.DragPoserError) as e:
-        opt.optimize(**d, n_iter=257)
+        opt.optimize(**d, n_iter=_lib.DP_MAX_ITERS + 1)
     assert e.value.code == _lib.DP_ERR_INVALID
     with pytest.raises(ValueError):
         opt.optimize(**{**d, "w": d["w"].double()}, n_iter=5)
@@ -317,8 +317,24 @@ def test_edge_sizes(opt, dev, golden_dir):
     assert e.value.code == _lib.DP_ERR_INVALID
     with pytest.raises(_lib.DragPoserError):
         opt.optimize(**d, n_iter=0)
-    o = opt.optimize(**{k: v[:16] for k, v in d.items()}, n_iter=256)  # DP_MAX_ITERS
+    o = opt.optimize(**{k: v[:16] for k, v in d.items()}, n_iter=256)  # the whole argument table of Adam scalars
     assert torch.isfinite(o["z"]).all() and (o["iters"] == 256).all()
+    # beyond the table (the reference has no cap on max_iter): the kernels continue Adam's two bias corrections in double on the device --
+    # 300 iterations against the C oracle, which computes them on the host for every iteration (dp_w4's LONG instantiations)
+    from oracle.analytic import AnalyticOracle
+
+    a = [g[k][:16] for k in KEYS]
+    want = AnalyticOracle(precision="f32").optimize(*a, 300)
+    with pytest.raises(_lib.DragPoserError) as e:  # the large-batch kernel reads the table only (include/dragposer.h)
+        opt.optimize(**{k: v[:16] for k, v in d.items()}, n_iter=300, kernel="w16")
+    assert e.value.code == _lib.DP_ERR_UNSUPPORTED
+    for kernel in ("w4", "auto"):
+        o = opt.optimize(**{k: v[:16] for k, v in d.items()}, n_iter=300, kernel=kernel)
+        err = np.linalg.norm(o["pos"].cpu().numpy() - want["pos"], axis=-1).max(axis=1) * 1000.0
+        assert (o["iters"] == 300).all() and np.sort(err)[-2] <= 0.05 and err.max() <= 5.0, (kernel, err)
+        np.testing.assert_allclose(o["loss"].cpu().numpy()[err <= 0.05], want["loss"][err <= 0.05], rtol=5e-3, atol=1e-6)
+    with pytest.raises(_lib.DragPoserError):
+        opt.optimize(**{k: v[:16] for k, v in d.items()}, n_iter=_lib.DP_MAX_ITERS + 1)
     reps = 4096  # 64 golden frames x 4096 = 262 144 frames
     big = {k: v.repeat((reps,) + (1,) * (v.dim() - 1)) for k, v in d.items()}
     for hint, kernel in ((0, "w4"), (6, "w4"), (0, "w16")):  # (the version-1 kernel hint is accepted and ignored)

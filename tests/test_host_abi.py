@@ -126,7 +126,7 @@ def test_argument_validation_and_status_codes(lib, golden_dir):
     b, keep = _batch(g, 4)
     r, o = _results(4)
     mt = g["meta"]
-    for bad, msg in ((dict(n_iter=0), b"n_iter"), (dict(n_iter=257), b"n_iter"), (dict(lr=0.0), b"Adam"), (dict(beta1=1.0), b"Adam"),
+    for bad, msg in ((dict(n_iter=0), b"n_iter"), (dict(n_iter=_lib.DP_MAX_ITERS + 1), b"n_iter"), (dict(lr=0.0), b"Adam"), (dict(beta1=1.0), b"Adam"),
                      (dict(eps=0.0), b"eps must be > 0"), (dict(kernel=7), b"kernel selector")):
         assert lib.dp_optimize(ctx, C.byref(b), C.byref(_params(mt, **bad)), C.byref(r), None) == _lib.DP_ERR_INVALID, bad
         assert msg in lib.dp_last_error(ctx), (bad, lib.dp_last_error(ctx))
