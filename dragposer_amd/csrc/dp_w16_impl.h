@@ -314,6 +314,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
         if (lane == 0) { *(unsigned long long*)(lds + L16_CLK) = c0; *(unsigned long long*)(lds + L16_CLK + 2) = r0; }
     }
+#ifdef W16_STAGGER // (the waves of a workgroup started W16_STAGGER x 64 cycles apart: see dp_w4.hip "Stagger")
+    for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(W16_STAGGER);
+#endif
     // (Two waves per SIMD run the same program from the same barrier; a start delay for the second half of the workgroup -- so that one
     //  wave's matrix phases fall on the other's vector phases -- was measured and changes nothing: profiles/r03_w16_stagger.txt.)
     const float* lbias = (const float*)lds + L16_BIAS;

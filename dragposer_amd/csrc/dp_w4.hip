@@ -1039,6 +1039,18 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 
     const f4 bias0T = splat(bias0), bias1T = splat(bias1), bias2aT = splat(bias2a), bias2bT = splat(bias2b); // C operands of the chains' first steps
     const f4 eT = {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f, i == 3 ? 1.f : 0.f}; // unit rows of the transposes
+    // ---- Stagger (round 5).  The four waves of a workgroup sit on four SIMDs and share nothing in the loop -- except the LDS: ~100 reads and
+    //      writes of 1 KB per wave and iteration (the frame blocks' J / T / G exchanges, bL2's streamed weights), half of the LDS's cycles.  Released
+    //      from one barrier the waves run the same instructions in lockstep, every burst of one collides with the same burst of the other three
+    //      (a dependent read that takes ~70 cycles alone waits for three others' kilobytes), and nothing ever separates them.  Started W4_STAGGER x
+    //      64 cycles apart -- about a quarter of an iteration: each wave's kinematics window falls into the others' matrix phases -- the launch is
+    //      5-7 % shorter on every configuration (profiles/r05_stagger_sweep.txt: 12 ... 36, seven workloads, six rounds each; 18 ... 22 is the
+    //      flat optimum, 20 the most even), the three sleeps included.  Outputs unchanged (a wave's arithmetic does not know when it runs).
+#ifndef W4_STAGGER
+#define W4_STAGGER 20
+#endif
+    if (W4_STAGGER > 0 && optimise)
+        for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(W4_STAGGER);
     JOut jo;
     Prof prof;
     prof.start();

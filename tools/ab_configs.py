@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONFIGS = {"S1 6 trackers x 50": dict(trackers=6, n_iter=50, lam=0.02), "S3 3 trackers x 100": dict(trackers=3, n_iter=100, lam=0.15),
            "4 trackers x 50": dict(trackers=4, n_iter=50, lam=0.125), "3 trackers x 50": dict(trackers=3, n_iter=50, lam=0.15),
-           "4 trackers x 100": dict(trackers=4, n_iter=100, lam=0.125)}
+           "4 trackers x 100": dict(trackers=4, n_iter=100, lam=0.125),
+           "S1 x 50, while-condition kernel": dict(trackers=6, n_iter=50, lam=0.02, early=True), "S1 1024 frames x 50": dict(trackers=6, n_iter=50, lam=0.02, frames=1024)}
 
 
 def child(lib):
@@ -35,16 +36,17 @@ def child(lib):
             for j in (3, 7):
                 b["tracked"][:, j] = 0; b["w"][:, j] = 0; b["tgt_pos"][:, j] = 0; b["tgt_rot"][:, j] = 0
         else:
-            b = R.synth_inputs(R.OracleModel(), 4096, trackers=c["trackers"])
+            b = R.synth_inputs(R.OracleModel(), c.get("frames", 4096), trackers=c["trackers"])
         d = to_device_batch(b, dev)
         names = ("z", "z_pre", "pose", "disp", "world_disp", "world_rot", "pos", "loss", "iters")
-        out = opt.optimize(**d, n_iter=c["n_iter"], lambda_tmp=c["lam"], outputs=names, kernel="w4")
+        kw = dict(stop_eps_pos=1e-30, stop_eps_rot=1e-30, min_loss_incr=-1e30) if c.get("early") else {}  # (the while-condition never fails: all iterations, through the early-stop instantiation)
+        out = opt.optimize(**d, n_iter=c["n_iter"], lambda_tmp=c["lam"], outputs=names, kernel="w4", **kw)
         for _ in range(int(60.0 / (0.14 * c["n_iter"] / 50)) + 1):
-            opt.optimize(**d, n_iter=c["n_iter"], lambda_tmp=c["lam"], outputs=names, out=out, kernel="w4")
+            opt.optimize(**d, n_iter=c["n_iter"], lambda_tmp=c["lam"], outputs=names, out=out, kernel="w4", **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(50):
-            opt.optimize(**d, n_iter=c["n_iter"], lambda_tmp=c["lam"], outputs=names, out=out, kernel="w4")
+            opt.optimize(**d, n_iter=c["n_iter"], lambda_tmp=c["lam"], outputs=names, out=out, kernel="w4", **kw)
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 50
