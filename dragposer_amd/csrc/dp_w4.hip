@@ -1144,6 +1144,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         }
         int o = lane;
         asm volatile("" : "+v"(o)); // opaque per iteration: keeps the streamed weight reads inside the loop
+        // (round 5, measured and not adopted: the streamed groups from global memory instead -- the L1 / L2 path is idle in the loop and the LDS is
+        //  what the four waves contend for --: +3.3 % as it stands, +4 % with every chunk requested a phase earlier; 20 KB per wave and iteration
+        //  does not live in the L1, and an L2 round trip is longer than any phase ahead the registers allow)
         const f4* w2 = (const f4*)(lds + L_IMG2) + o;
 
         // ================= L0: a0 = lrelu(A0 z + c0)
