@@ -58,8 +58,11 @@ constexpr int FB_END = FB_SPOS + 68;
 constexpr int QS_DISP = ITEM_DISP, QS_IDENT = 30, QS_TRASH = 31, WT_ZERO = 30, WT_TRASH = 31;
 // the four frames of a wave sit in the four lanes of every quad: block stride = 16 banks (mod 64) apart, so that the
 // quad's 16-byte accesses to the same row of four blocks never share a bank
-constexpr int FB_STRIDE = ((FB_END - 16 + 63) / 64) * 64 + 16;
-static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == 16 && FB_LP % 4 == 0 && FB_TI % 4 == 0 && FB_ZPRE % 4 == 0 && FB_ES % 4 == 0, "frame block layout");
+#ifndef W4_FB_RES
+#define W4_FB_RES 16 // (diagnostic: other residues of the block stride mod 64 banks; multiples of 4)
+#endif
+constexpr int FB_STRIDE = ((FB_END - W4_FB_RES + 63) / 64) * 64 + W4_FB_RES;
+static_assert(FB_STRIDE >= FB_END && FB_STRIDE % 64 == W4_FB_RES && W4_FB_RES % 4 == 0 && FB_LP % 4 == 0 && FB_TI % 4 == 0 && FB_ZPRE % 4 == 0 && FB_ES % 4 == 0, "frame block layout");
 
 constexpr int GR_B2 = S_B2 / 4, NG_B2 = 26;     // the streamed product: first group, groups
 constexpr int L_IMG2 = 0;                       // bL2 image [26][64][4]
