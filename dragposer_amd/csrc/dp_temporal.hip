@@ -56,31 +56,44 @@ DEV f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f3
 // dimension of an MFMA).  NS = 1: one sequence, its T <= 32 tokens in rows 0 .. T-1 (the second tile only when T > 16).
 // NS = 2: two sequences, sequence s in tile s, T <= 16 tokens each -- every token-wise product then serves both with one
 // fetch of its weights.
-template <int NS> DEV int n_ttiles(int T) { return NS == 1 ? (T + 15) >> 4 : NS; }
-template <int NS> DEV int tile_tokens(int tt, int T) { return NS == 1 ? min(16, T - 16 * tt) : T; } // valid rows of tile tt
-template <int NS> DEV int pe_row(int tt, int tl) { return NS == 1 ? 16 * tt + tl : tl; }            // position of row tl of tile tt
+// Round 5: the rows a sequence gets are a PARAMETER of every phase (R, a power of two; NS >= 2 only): R = 16 is the tile per sequence above; R = 8
+// puts two sequences into ONE tile (sequence s in rows 8 s .. 8 s + T - 1) for the decoder calls over at most 8 target tokens -- the first call of
+// every block has ONE token per sequence, and a tile of 16 rows per sequence spends 15/16 of its matrix work on nothing.
+template <int NS> DEV int rows_per_seq(int T) { return (NS == 2 && T <= 8) ? 8 : 16; } // (derived from the token count wherever it is needed: nothing to keep alive)
+template <int NS> DEV int n_ttiles(int T, int R) { return NS == 1 ? (T + 15) >> 4 : (NS * R + 15) >> 4; }
+template <int NS> DEV bool row_valid(int g, int T, int R) { return NS == 1 ? g < T : (g & (R - 1)) < T; } // row g = 16 tile + row in tile
+template <int NS> DEV int row_pos(int g, int R) { return NS == 1 ? g : g & (R - 1); }                      // its position in its sequence
+template <int NS> DEV int row_of(int g, int R, int R2)
+{ // the same token in a layout of R2 rows per sequence (R, R2 in {8, 16}: no integer division in the kernel)
+    if (NS == 1 || R == R2) return g;
+    return R == 8 ? ((g >> 3) << 4) + (g & 7) : ((g >> 4) << 3) + (g & 15);
+}
 
 // out[t][n] = b[col0 + n] + sum_k in[t][k] * wT[k][col0 + n] (+ pe[pos(t)][n])   (n < N, k < K <= 4 KS; wT has ldw columns)
 // One 16 x 16 output tile per wave and turn: A[token][k] from LDS, B[k][n] one word per lane and K-step -- all KS loads
 // of a tile in flight together.
 template <int KS, int NS>
 DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* wT, int ldw, int col0, const float* b, int N, int K,
-             const float* pe = nullptr)
-{
+             const float* pe = nullptr, int Rin = 0)
+{ // rows per sequence of `out`: rows_per_seq(T); of `in`: Rin (0: the same)
+    const int R = rows_per_seq<NS>(T);
+    if (Rin == 0) Rin = R;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // opaque per call: the per-lane weight addresses are recomputed (a few VALU operations) instead
                                    // of being hoisted out of the layer loops into registers the kernel does not have
     const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
-    const int ntiles = (N + 15) >> 4, jobs = ntiles * n_ttiles<NS>(T);
+    const int ntiles = (N + 15) >> 4, jobs = ntiles * n_ttiles<NS>(T, R);
 #pragma unroll 1
     for (int job = wave; job < jobs; job += NWV) {
-        const int nt = job % ntiles, tt = job / ntiles, n = 16 * nt + l16, tv = tile_tokens<NS>(tt, T);
+        const int nt = job % ntiles, tt = job / ntiles, n = 16 * nt + l16;
+        const bool rv = row_valid<NS>(16 * tt + l16, T, R);
+        const int rin = row_of<NS>(16 * tt + l16, R, Rin);
         float bw[KS], av[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = 4 * ks + q;
             bw[ks] = (k < K && n < N) ? wT[(size_t)k * ldw + col0 + n] : 0.f;
-            av[ks] = (k < K && l16 < tv) ? in[(16 * tt + l16) * ldi + k] : 0.f;
+            av[ks] = (k < K && rv) ? in[rin * ldi + k] : 0.f;
         }
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -92,8 +105,8 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
             const float bias = b[col0 + n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int tl = 4 * q + r;
-                if (tl < tv) out[(16 * tt + tl) * ldo + n] = acc0[r] + acc1[r] + bias + (pe ? pe[pe_row<NS>(tt, tl) * D + n] : 0.f);
+                const int g = 16 * tt + 4 * q + r;
+                if (row_valid<NS>(g, T, R)) out[g * ldo + n] = acc0[r] + acc1[r] + bias + (pe ? pe[row_pos<NS>(g, R) * D + n] : 0.f);
             }
         }
     }
@@ -104,7 +117,8 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
 // sequences are the rows of one MFMA tile
 template <int NS>
 DEV void next_token(float* tok, float* preds, const float* x, int T, int it, bool feed, const float* wT, const float* b)
-{
+{ // (x in the layout of rows_per_seq(T) rows per sequence; tok keeps 16 rows per sequence whatever the calls' layouts are)
+    const int R = rows_per_seq<NS>(T);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
@@ -115,7 +129,7 @@ DEV void next_token(float* tok, float* preds, const float* x, int T, int it, boo
         for (int ks = 0; ks < D / 4; ++ks) {
             const int k = 4 * ks + q;
             bw[ks] = n < LAT ? wT[k * LAT + n] : 0.f;
-            av[ks] = l16 < NS ? x[((NS == 1 ? 0 : 16 * l16) + T - 1) * D + k] : 0.f;
+            av[ks] = l16 < NS ? x[((NS == 1 ? 0 : R * l16) + T - 1) * D + k] : 0.f;
         }
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -169,13 +183,16 @@ DEV float wave_sum(float v)
 template <int NS>
 DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = rows_per_seq<NS>(T);
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (as in lin: the per-lane addresses of the two parameter rows are not to be hoisted out of the call loop and spilled)
+    const int wave = threadIdx.x >> 6;
     const bool live = lane < D;
     const float gc = live ? g[lane] : 0.f, bc = live ? b[lane] : 0.f;
-    const int rows = 16 * n_ttiles<NS>(T);
+    const int rows = 16 * n_ttiles<NS>(T, R);
 #pragma unroll 1
     for (int t = wave; t < rows; t += NWV) {
-        if ((t & 15) >= tile_tokens<NS>(t >> 4, T)) continue; // (uniform per wave)
+        if (!row_valid<NS>(t, T, R)) continue; // (uniform per wave)
         float v = 0.f;
         if (live) v = x[t * D + lane] + (o ? o[t * D + lane] : 0.f);
         const float mean = wave_sum(v) * (1.f / D);
@@ -190,23 +207,25 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 // tiles) are dealt to the waves; columns 0..47 take the query tokens, the rest the key / value tokens.
 template <int NS>
 DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* wT, const float* b)
-{
+{ // (q rows in the layout of rows_per_seq(Tq) rows per sequence, k / v rows in that of rows_per_seq(Tk))
+    const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
     const int wave = threadIdx.x >> 6, l16 = lane & 15, qd = lane >> 4;
-    const int ttq = n_ttiles<NS>(Tq), ttk = n_ttiles<NS>(Tk), jobs = 3 * ttq + 6 * ttk;
+    const int ttq = n_ttiles<NS>(Tq, Rq), ttk = n_ttiles<NS>(Tk, Rk), jobs = 3 * ttq + 6 * ttk;
 #pragma unroll 1
     for (int job = wave; job < jobs; job += NWV) {
         const bool isq = job < 3 * ttq;
         const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : j2 / 6;
         const float* in = isq ? xq : xkv;
-        const int tv = tile_tokens<NS>(tt, isq ? Tq : Tk), n = 16 * nt + l16;
+        const int Tj = isq ? Tq : Tk, Rj = isq ? Rq : Rk, n = 16 * nt + l16;
+        const bool rv = row_valid<NS>(16 * tt + l16, Tj, Rj);
         float bw[D / 4], av[D / 4];
 #pragma unroll
         for (int ks = 0; ks < D / 4; ++ks) {
             const int k = 4 * ks + qd;
             bw[ks] = wT[k * 3 * D + n];
-            av[ks] = l16 < tv ? in[(16 * tt + l16) * D + k] : 0.f;
+            av[ks] = rv ? in[(16 * tt + l16) * D + k] : 0.f;
         }
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -218,8 +237,8 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
         float* out = qkv + (n / D) * (MAXT * D) + (n % D); // q, k, v are consecutive [MAXT][D] arrays
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int tl = 4 * qd + r;
-            if (tl < tv) out[(16 * tt + tl) * D] = acc0[r] + acc1[r] + bias;
+            const int g = 16 * tt + 4 * qd + r;
+            if (row_valid<NS>(g, Tj, Rj)) out[g * D] = acc0[r] + acc1[r] + bias;
         }
     }
     __syncthreads();
@@ -233,10 +252,11 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
 template <int NS>
 DEV void attention(float* ao, const float* q, const float* k, const float* v, float* sc, int Tq, int Tk)
 {
+    const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = wave & (NHD - 1), sq = wave / NHD; // NS = 1: waves 0..3, one per head; NS = 2: wave = 4 * sequence + head
     if (sq < NS) {
-        q += 16 * sq * D; k += 16 * sq * D; v += 16 * sq * D; ao += 16 * sq * D; // (the sequence's tile)
+        q += Rq * sq * D; k += Rk * sq * D; v += Rk * sq * D; ao += Rq * sq * D; // (the sequence's rows)
         const float scale = 1.f / sqrtf((float)HD);
         const int j = lane & 15, r = lane >> 4;
         const bool live0 = j < Tk, live1 = j + 16 < Tk;
@@ -318,24 +338,26 @@ DEV void ffn_load(f4 (&im)[7], const f4* img, int nt, int ntiles)
 // PREFETCH: a wave keeps the images of three tiles in flight (84 registers: the one-workgroup-per-CU kernel, where a SIMD
 // has two waves to hide an L2 round trip behind 768 cycles of MFMA per tile); otherwise one, and four waves per SIMD.
 // NS = 2: every tile image serves the token tiles of both sequences.
-template <bool PREFETCH, int NS>
+template <bool PREFETCH, int NS, int R = 16>
 DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red)
-{
+{ // (R, the rows per sequence, is a compile-time constant here: as a run-time value it cost the 128-register instantiation 8 spills)
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
     const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
     const int ntiles = (F + 15) >> 4;
     const f4* img = (const f4*)(w + pack) + lane;
-    constexpr int NG = NS == 1 ? 1 : NS; // token tiles that share one pass over the weights
+    constexpr int NG = NS == 1 ? 1 : (NS * R + 15) / 16; // token tiles that share one pass over the weights (R = 8: ONE tile for the two sequences)
+    const int ntt = n_ttiles<NS>(T, R);
 #pragma unroll 1
-    for (int tt0 = 0; tt0 < n_ttiles<NS>(T); tt0 += NG) {
+    for (int tt0 = 0; tt0 < ntt; tt0 += NG) {
+        constexpr int ng = NG;
         float xb[NG][D / 4]; // B operand of the first product: X^T[k][token]
         f4 acc[NG][3];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int tv = tile_tokens<NS>(tt0 + g, T);
+            const bool rv = g < ng && row_valid<NS>(16 * (tt0 + g) + l16, T, R);
 #pragma unroll
-            for (int ks = 0; ks < D / 4; ++ks) xb[g][ks] = l16 < tv ? x[(16 * (tt0 + g) + l16) * D + 4 * ks + q] : 0.f;
+            for (int ks = 0; ks < D / 4; ++ks) xb[g][ks] = rv ? x[(16 * (tt0 + g) + l16) * D + 4 * ks + q] : 0.f;
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
         }
@@ -347,17 +369,17 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
             while (nt < ntiles) {
                 ffn_load(b2, img, nt + 2 * NWV, ntiles);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) ffn_tile(b0, xb[g], acc[g]);
+                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b0, xb[g], acc[g]);
                 nt += NWV;
                 if (nt >= ntiles) break;
                 ffn_load(b0, img, nt + 2 * NWV, ntiles);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) ffn_tile(b1, xb[g], acc[g]);
+                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b1, xb[g], acc[g]);
                 nt += NWV;
                 if (nt >= ntiles) break;
                 ffn_load(b1, img, nt + 2 * NWV, ntiles);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) ffn_tile(b2, xb[g], acc[g]);
+                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b2, xb[g], acc[g]);
                 nt += NWV;
             }
         } else {
@@ -366,20 +388,21 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
                 f4 cur[7];
                 ffn_load(cur, img, nt, ntiles);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) ffn_tile(cur, xb[g], acc[g]);
+                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(cur, xb[g], acc[g]);
             }
         }
         // the waves' partial outputs, one token tile at a time through the reduction buffer: lane (channel l16 of tile ct,
         // token group q), register r = token 4 q + r
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int tt = tt0 + g, tv = tile_tokens<NS>(tt, T);
+            if (g >= ng) break; // (uniform)
+            const int tt = tt0 + g;
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) *(f4*)(red + ((wave * 3 + ct) * 64 + lane) * 4) = acc[g][ct];
             __syncthreads();
             for (int idx = threadIdx.x; idx < 16 * D; idx += NT) {
                 const int tl = idx / D, c = idx - tl * D;
-                if (tl < tv) {
+                if (row_valid<NS>(16 * tt + tl, T, R)) {
                     const int slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
                     float sum = w[l2b + c];
 #pragma unroll
@@ -431,12 +454,13 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     __syncthreads();
 
     // ---- encoder, once (the memory is the same for every autoregressive call)
-    lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe);
+    lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
     for (int l = 0; l < a.n_enc; ++l) {
         const TLayer L = ((const TLayer*)(w + a.enc_tab))[l];
         mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln<NS>(x, o, Te, w + L.n1w, w + L.n1b);
-        ffn<OCC == 2, NS>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
+        if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform; a history of at most 8 tokens)
+        else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
         add_ln<NS>(x, o, Te, w + L.n2w, w + L.n2b);
     }
     add_ln<NS>(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
@@ -446,14 +470,17 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     // ---- autoregressive calls (drag_pose.py:274-279): call i sees i + 1 target tokens, keeps the last position's output
     for (int it = 0; it < n_steps; ++it) {
         const int T = it + 1;
-        lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe);
+        // (the activations of a call over at most 8 tokens take 8 rows per sequence: two sequences share a tile -- rows_per_seq; the token buffer
+        //  keeps 16, the memory the layout of its own token count)
+        lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe, 16);
         for (int l = 0; l < a.n_dec; ++l) {
             const TLayer L = ((const TLayer*)(w + a.dec_tab))[l];
             mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, w + L.n1w, w + L.n1b);
             mha<NS>(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, w + L.n2w, w + L.n2b);
-            ffn<OCC == 2, NS>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
+            if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform)
+            else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
             add_ln<NS>(x, o, T, w + L.n3w, w + L.n3b);
         }
         add_ln<NS>(x, nullptr, T, w + a.decn_w, w + a.decn_b);
