@@ -338,8 +338,8 @@ def main():
             opt.optimize(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
         ev1.record()
         torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
+        dt = time.perf_counter() - t0  # this rank's K steps, device work complete; the job's time is the MAX over the ranks (reduce_stats below) --
+        barrier()                      # which is what the closing barrier would make every rank read anyway, plus the barrier's own latency
         return dt, ev0.elapsed_time(ev1) / steps, sclk_ghz(out["clock"]), out
 
     dt, kern_ms, sclk, out = timed_pass(batch, args.kernel, args.steps, args.warmup)
