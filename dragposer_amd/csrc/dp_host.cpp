@@ -718,8 +718,10 @@ extern "C" int dp_auto_kernel(const dp_ctx* ctx, int n_frames)
 #ifdef DP_REF8_BUILD
     return DP_KERNEL_W4;
 #else
-    // more than one round of dp_w4's 16 frames per CU: dp_w16 (where its slot map fits the skeleton)
-    return ctx->d_w16img != nullptr && n_frames > ctx->n_cu * 16 ? DP_KERNEL_W16 : DP_KERNEL_W4;
+    // more than TWO rounds of dp_w4's 16 frames per CU: dp_w16 (where its slot map fits the skeleton).  Up to two rounds dp_w4 is the faster one
+    // since round 5 (its waves' staggered start: 0.252 ms for 8192 frames against dp_w16's 0.273 at the steady clock, 0.251 against 0.274 at 6144,
+    // profiles/r05_batch_sweep.txt; equal from an idle GPU); from three rounds on dp_w16 wins by 1.3x and more
+    return ctx->d_w16img != nullptr && n_frames > ctx->n_cu * 32 ? DP_KERNEL_W16 : DP_KERNEL_W4;
 #endif
 }
 

@@ -128,7 +128,7 @@ class LatentOptimizer:
         (drag_pose.py:300-304) and `iters` reports how many iterations it took (n_iter = max_iter).
         `max_trackers`: ignored (a kernel-selection hint of version 1; kept so that old callers keep working).
         `kernel`: "auto" | "w4" (4 frames per wave, fp32 MFMA) | "w16" (16 frames per wave, decoder on bf16 MFMA in split
-        precision; what "auto" picks beyond 4096 frames) -- include/dragposer.h: DP_KERNEL_*.
+        precision; what "auto" picks beyond 8192 frames: two rounds of "w4") -- include/dragposer.h: DP_KERNEL_*.
         `validate_targets`: check that every tracked joint's tgt_rot is a rotation matrix (the kernel evaluates the
         reference's |R - T|^2 in its quaternion form, equal only for orthonormal det +1 targets: include/dragposer.h) --
         costs a device reduction and a host synchronisation, so it is off by default."""

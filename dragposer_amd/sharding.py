@@ -20,7 +20,7 @@ def pick_kernel(optimizer, n_total, world):
     """The kernel every rank passes to `LatentOptimizer.optimize(kernel=...)` when ONE batch of n_total frames is cut into `world`
     shards: the library's own choice (dp_auto_kernel) for the LARGEST shard.  kernel="auto" decides per launch from the launch's
     frame count, and the two kernels differ in the last bits of their arithmetic -- left to itself, a rank whose shard falls on the
-    other side of the threshold (16 frames per CU) than its neighbour's would compute its frames in other arithmetic than they do.
+    other side of the threshold (32 frames per CU) than its neighbour's would compute its frames in other arithmetic than they do.
     What this does NOT promise: that the sharded result equals the one-GPU result of the whole batch bit for bit -- that batch, if it
     is larger than one round of dp_w4, runs dp_w16 on one GPU and (shards being smaller) dp_w4 when sharded; both are held to the same
     reference runs, and a caller that needs the bits to agree pins kernel="w16" (or "w4") on both sides."""

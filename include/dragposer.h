@@ -143,10 +143,11 @@ typedef struct dp_params {
  *   DP_KERNEL_W4   4 frames per wavefront, fp32 MFMA (v_mfma_f32_4x4x1): every launch shape, forward-only, whole sequences.
  *   DP_KERNEL_W16  16 frames per wavefront, decoder on v_mfma_f32_16x16x32_bf16 in split precision (every fp32 operand the
  *                  exact sum of three bf16 terms, six term products per block accumulated in fp32), fixed iteration count or
- *                  early stop; the reference's 22-joint skeleton only (DP_ERR_UNSUPPORTED otherwise).  Pays as soon as W4 needs a
- *                  second round (it holds 16 frames per CU at a time: 4096 on an MI355X).
+ *                  early stop; the reference's 22-joint skeleton only (DP_ERR_UNSUPPORTED otherwise).  Pays when W4 needs a THIRD round
+ *                  (W4 holds 16 frames per CU at a time: 4096 on an MI355X; it runs two rounds in 0.25 ms, W16 any batch up to 16 384
+ *                  frames in 0.27-0.28 ms).
  *                  n_iter <= 256 (the kernel-argument table of Adam scalars; beyond it: DP_ERR_UNSUPPORTED, DP_KERNEL_AUTO takes W4 then).
- *   DP_KERNEL_AUTO W16 for more than 16 frames per CU (> 4096 on an MI355X), either weight type, with or without early stop (both
+ *   DP_KERNEL_AUTO W16 for more than 32 frames per CU (> 8192 on an MI355X; > 4096 before 0.5.0), either weight type, with or without early stop (both
  *                  kernels compute in fp32-equivalent arithmetic and are held to the same reference runs,
  *                  tests/test_hip_parity.py::test_full_size_batch_properties, tests/test_hip_w16.py); W4 otherwise -- BASELINE's
  *                  1024- and 4096-frame batches, every sequence launch. */

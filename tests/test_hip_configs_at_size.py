@@ -146,9 +146,10 @@ def test_kernels_agree_with_each_other_at_size(opts, dev, golden_dir, name):
 #     tests/sensitivity.py (a LeakyReLU pre-activation within rounding of zero on its trajectory; a gradient component within rounding of
 #     zero under Adam's first steps);
 #   * there are at most 2 x (the pair's own count) + 2 of them.
-@pytest.mark.parametrize("how", ["one_launch", "shards_of_1024"])
+@pytest.mark.parametrize("how", ["one_launch", "one_launch_w16", "shards_of_1024"])
 def test_config3_whole_batch_against_the_reference(opts, dev, golden_dir, how):
-    """one_launch: the 8192 frames on ONE GPU (DP_KERNEL_AUTO: dp_w16 beyond 4096 frames).  shards_of_1024: the eight contiguous shards a
+    """one_launch: the 8192 frames on ONE GPU as DP_KERNEL_AUTO runs them (two rounds of dp_w4 since round 5); one_launch_w16: through the large-batch
+    kernel (what AUTO took for this size through round 4, and takes beyond it).  shards_of_1024: the eight contiguous shards a
     node's eight ranks get (dragposer_amd.sharding.shard_bounds), each in its own launch with the kernel sharding.pick_kernel pins for the
     batch (dp_w4 at 1024 frames per GPU) -- every rank's slice held to the reference's rows of that slice, which is what
     tests/test_multi_gpu.py holds a real rank to when a node is there."""
@@ -164,9 +165,10 @@ def test_config3_whole_batch_against_the_reference(opts, dev, golden_dir, how):
     b["tgt_pos"][:, T6], b["tgt_rot"][:, T6] = ref["tgt_pos6"], ref["tgt_rot6"]
     assert _digest(b) == mt["digest"], "the recipe's inputs are not the ones the reference was run on"
     opt = opts["none"]
-    if how == "one_launch":
-        o = {k: v.cpu().numpy() for k, v in opt.optimize(**to_device_batch(b, dev), n_iter=50, lambda_tmp=mt["lambda_tmp"]).items()}
-        assert opt.kernel_geometry()[0] == 64  # dp_w16, one wave of 16 frames per SIMD
+    if how.startswith("one_launch"):
+        kern = "w16" if how.endswith("w16") else "auto"
+        o = {k: v.cpu().numpy() for k, v in opt.optimize(**to_device_batch(b, dev), n_iter=50, lambda_tmp=mt["lambda_tmp"], kernel=kern).items()}
+        assert opt.kernel_geometry()[0] == (64 if kern == "w16" else 16)  # dp_w16: one wave of 16 frames per SIMD; dp_w4: 4 waves of 4 frames
     else:
         kern = pick_kernel(opt, B, 8)
         assert kern == "w4"

@@ -123,7 +123,7 @@ def test_large_mixed_batch_agrees_with_the_fp32_mfma_kernel(opts, dev):
     m = R.OracleModel(weight_rounding="bf16")
     b = R.synth_inputs(m, 16384, mixed=True)
     d = to_device_batch(b, dev)
-    a16 = _run(opts["bf16"], d, n_iter=50, kernel="auto")  # more than one round of dp_w4, fixed count: w16
+    a16 = _run(opts["bf16"], d, n_iter=50, kernel="auto")  # more than two rounds of dp_w4, fixed count: w16
     assert opts["bf16"].kernel_geometry()[:2] == (64, 256)  # 16384 frames = one wave per SIMD
     a4 = _run(opts["bf16"], d, n_iter=50, kernel="w4")
     assert opts["bf16"].kernel_geometry()[0] == 16
@@ -227,7 +227,7 @@ def test_early_stop_at_size_and_kernel_choice(opts, dev):
 
     m = R.OracleModel()
     kw = dict(n_iter=60, lambda_tmp=0.02, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5)
-    for B, fpw, wd in ((8192, 64, "none"), (20480, 128, "none"), (8192, 64, "bf16")):  # (bf16: BASELINE config 5's mixed tracker counts)
+    for B, fpw, wd in ((12288, 64, "none"), (20480, 128, "none"), (12288, 64, "bf16")):  # (more than two rounds of dp_w4; bf16: BASELINE config 5's mixed tracker counts)
         o = opts[wd]
         d = to_device_batch(R.synth_inputs(R.OracleModel(weight_rounding=wd), B, seed=9, mixed=(wd == "bf16")), dev)
         a = _run(o, d, kernel="auto", **kw)
@@ -254,6 +254,7 @@ def test_launches_are_graph_capturable(opts, dev):
     d = to_device_batch(R.synth_inputs(R.OracleModel(), 8192, seed=4), dev)
     for kw in (dict(n_iter=20), dict(n_iter=40, stop_eps_pos=1e-4, stop_eps_rot=1e-2, min_loss_incr=1e-5)):
         out = o.allocate_outputs(8192)
+        kw = dict(kw, kernel="w16")
         want = {k: v.clone() for k, v in o.optimize(**d, out=out, **kw).items()}
         assert o.kernel_geometry()[0] == 64
         for v in out.values():

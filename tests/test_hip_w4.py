@@ -255,15 +255,15 @@ def test_two_contexts_shard_one_batch(opt, dev, golden_dir):
 
 
 def test_shards_of_one_batch_run_one_arithmetic(opt, dev):
-    """kernel="auto" chooses per launch from the launch's own frame count (dp_auto_kernel: dp_w16 beyond 16 frames per CU), and the
-    two kernels differ in their last bits -- so a batch whose shards fall on both sides of the threshold (8193 frames on two ranks:
-    4097 and 4096) would be computed in two arithmetics if every rank asked for "auto".  dragposer_amd.sharding.pick_kernel pins the
+    """kernel="auto" chooses per launch from the launch's own frame count (dp_auto_kernel: dp_w16 beyond 32 frames per CU, two rounds of
+    dp_w4), and the two kernels differ in their last bits -- so a batch whose shards fall on both sides of the threshold (16 385 frames on two
+    ranks: 8193 and 8192) would be computed in two arithmetics if every rank asked for "auto".  dragposer_amd.sharding.pick_kernel pins the
     library's choice for the largest shard on every rank: shard rows then equal, bit for bit, the rows of the whole batch run with
     that kernel."""
     from dragposer_amd.optimizer import to_device_batch
     from dragposer_amd.sharding import pick_kernel, shard_bounds
 
-    per_round = opt.auto_kernel(1) == "w4" and next(n for n in (1024, 2048, 4096, 4864, 8192) if opt.auto_kernel(n + 1) == "w16")  # 16 frames per CU
+    per_round = opt.auto_kernel(1) == "w4" and next(n for n in (1024, 2048, 4096, 4864, 8192) if opt.auto_kernel(n + 1) == "w16")  # 32 frames per CU
     assert opt.auto_kernel(per_round) == "w4"
     n, world = 2 * per_round + 1, 2
     b = R.synth_inputs(R.OracleModel(), n, seed=21)
