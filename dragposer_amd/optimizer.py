@@ -50,6 +50,24 @@ def _check(t, name, shape, dtype, device):
     return t.data_ptr()
 
 
+class LaunchPlan:
+    """A dp_optimize call with its arguments already checked and marshalled (LatentOptimizer.plan).  Holds the input and result
+    tensors alive; `plan()` launches on torch's current stream of the optimiser's device and returns the result tensors."""
+
+    __slots__ = ("_opt", "_b", "_p", "_r", "results", "_inputs", "_fn", "_ctx", "_dev")
+
+    def __init__(self, opt, batch, params, res, tensors, inputs):
+        self._opt, self.results, self._inputs = opt, tensors, inputs
+        self._b, self._p, self._r = C.byref(batch), C.byref(params), C.byref(res)  # (byref objects keep their structs alive)
+        self._fn, self._ctx, self._dev = opt.lib.dp_optimize, opt.ctx, opt.device
+
+    def __call__(self):
+        rc = self._fn(self._ctx, self._b, self._p, self._r, torch.cuda.current_stream(self._dev).cuda_stream)
+        if rc != _lib.DP_OK:
+            self._opt._fail(rc)
+        return self.results
+
+
 class LatentOptimizer:
     """One context per device.  Not thread-safe (same contract as the C ABI)."""
 
@@ -132,6 +150,22 @@ class LatentOptimizer:
         `validate_targets`: check that every tracked joint's tgt_rot is a rotation matrix (the kernel evaluates the
         reference's |R - T|^2 in its quaternion form, equal only for orthonormal det +1 targets: include/dragposer.h) --
         costs a device reduction and a host synchronisation, so it is off by default."""
+        plan = self.plan(z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter, lr, betas, eps, lambda_rot, lambda_tmp, stop_eps_pos,
+                         stop_eps_rot, min_loss_incr, max_trackers, outputs, out, validate_targets, kernel)
+        if _debug is not None:
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self.lib.dp_optimize_debug(self.ctx, plan._b, plan._p, plan._r, C.c_void_p(_debug.data_ptr()), stream)
+            if rc != _lib.DP_OK:
+                self._fail(rc)
+            return plan.results
+        return plan()
+
+    def plan(self, z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked, n_iter=50, lr=1e-2, betas=(0.9, 0.999),
+             eps=1e-8, lambda_rot=1.0, lambda_tmp=0.02, stop_eps_pos=0.0, stop_eps_rot=0.0, min_loss_incr=None,
+             max_trackers=0, outputs=None, out=None, validate_targets=False, kernel="auto"):
+        """`optimize`'s arguments checked and marshalled ONCE: returns a LaunchPlan whose call launches dp_optimize over the same
+        tensors (read at launch time: refill them in place between calls) into the same result tensors, on torch's current stream --
+        a caller that steps the same buffers every frame pays one ctypes call per launch instead of the checks and struct filling."""
         B = int(z0.shape[0])
         dev = self.device
         if validate_targets:
@@ -153,15 +187,7 @@ class LatentOptimizer:
                           kernel={"auto": _lib.DP_KERNEL_AUTO, "w4": _lib.DP_KERNEL_W4, "w16": _lib.DP_KERNEL_W16}[kernel])
         names = tuple(outputs) if outputs is not None else tuple(_OUT_SPECS)
         res, tensors = self._outputs(B, names, out)
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if _debug is not None:
-            rc = self.lib.dp_optimize_debug(self.ctx, C.byref(batch), C.byref(p), C.byref(res),
-                                            C.c_void_p(_debug.data_ptr()), stream)
-        else:
-            rc = self.lib.dp_optimize(self.ctx, C.byref(batch), C.byref(p), C.byref(res), stream)
-        if rc != _lib.DP_OK:
-            self._fail(rc)
-        return tensors
+        return LaunchPlan(self, batch, p, res, tensors, (z0, z_tgt, cur_rot, tgt_pos, tgt_rot, w, tracked))
 
     def forward(self, z, cur_rot, outputs=("pose", "disp", "world_disp", "world_rot", "pos", "rot"), out=None):
         """decode + FK of z [B,24] under cur_rot [B,4] (no loss, no update)."""

@@ -206,6 +206,32 @@ def test_ragged_batches_equal_full_batch_rows(opt, golden_dir, B):
         np.testing.assert_array_equal(sub[k], full[k][:B])  # a frame's result never depends on its batch
 
 
+def test_launch_plan_repeats_the_call_over_the_same_buffers(opt, golden_dir):
+    """LatentOptimizer.plan: arguments marshalled once, then one dp_optimize call per `plan()`.  Same bits as `optimize`; the inputs are
+    read at launch time, so refilling them in place moves the result; a plan over bad arguments is refused when it is made."""
+    from dragposer_amd.optimizer import to_device_batch
+
+    g = R.load_golden(os.path.join(golden_dir, "s1.npz"))
+    want = _run(opt, g, 20, 0.02)
+    b = to_device_batch(g, opt.device)
+    plan = opt.plan(**b, n_iter=20, lambda_tmp=0.02)
+    out = plan()
+    assert out is plan.results and set(out) == set(want)
+    torch.cuda.synchronize()
+    for k in ("z", "pos", "pose", "loss", "iters", "status"):
+        np.testing.assert_array_equal(out[k].cpu().numpy(), want[k])
+    first = out["z"].clone()
+    b["z0"].copy_(torch.roll(b["z0"], 1, 0))  # in place: the plan holds the pointer, not a copy
+    plan()
+    torch.cuda.synchronize()
+    g2 = {k: g[k] for k in KEYS}
+    g2["z0"] = np.roll(g["z0"], 1, 0)
+    np.testing.assert_array_equal(out["z"].cpu().numpy(), _run(opt, g2, 20, 0.02)["z"])
+    assert not torch.equal(first, out["z"])
+    with pytest.raises(ValueError):
+        opt.plan(**{**b, "z0": b["z0"][:, :23]}, n_iter=20)
+
+
 @pytest.mark.parametrize("kernel", ["auto", "w16"])
 def test_full_size_batch_properties(opt, dev, golden_dir, kernel):
     """BASELINE's headline batch (4096 frames x 50 iterations): determinism, batch-position invariance, and parity on EVERY

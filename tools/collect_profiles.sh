@@ -19,8 +19,8 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "S
 done
 python3 tools/pmc_summary.py $O/pmc_per_launch.json $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 $O/pmc6 $O/pmc7 > /dev/null
 # 3. batch sweep
-# (the library's own kernel choice: dp_w4 up to 4096 frames, dp_w16 beyond; then dp_w4 forced at the large sizes for comparison)
-for spec in 256:auto 1024:auto 2048:auto 4096:auto 6144:auto 8192:auto 16384:auto 65536:auto 6144:w4 8192:w4 16384:w4 65536:w4; do
+# (the library's own kernel choice: dp_w4 up to 8192 frames = two rounds, dp_w16 beyond; then the other kernel forced at the sizes around the threshold)
+for spec in 256:auto 1024:auto 2048:auto 4096:auto 6144:auto 8192:auto 12288:auto 16384:auto 65536:auto 6144:w16 8192:w16 12288:w4 16384:w4 65536:w4; do
   fr=${spec%%:*}; kn=${spec##*:}
   python3 bench.py --frames $fr --kernel $kn --steps 20 --warmup 3 --no-cpu-baseline --no-parity --traffic none | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print($fr, '--kernel $kn:', '%.2f M frames/s' % (j['value']/1e6), 'frac %.4f' % r['frac'], 'kernel_ms %.4f' % r['kernel_ms'], r['kernel'])"
 done > $O/batch_sweep.txt
