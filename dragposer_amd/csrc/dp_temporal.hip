@@ -46,9 +46,28 @@ struct TArgs {
     const float *latent_buf, *disp_buf, *heights_buf;
     float* target;
     int H, n_seq, window;
+    // a TEAM of G workgroups per sequence (few sequences: latency; below): the exchange area of the handle, the tag base of this launch
+    float* xch;
+    int* tstatus;
+    unsigned epoch0;
+    int G;
 };
 
 #define DEV __device__ __forceinline__
+
+// Diagnostic build (-DDPT_STAMPS, tools/temporal_phases.sh): thread 0 of workgroup 0 records (phase id, s_memtime) at every phase boundary
+#ifdef DPT_STAMPS
+__device__ unsigned long long g_stamps[4096];
+__device__ int g_nstamps;
+#define STAMP(id)                                                                                                          \
+    do {                                                                                                                   \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g_nstamps < 4096) {                                                     \
+            g_stamps[g_nstamps++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull); \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
 
 DEV f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -303,9 +322,62 @@ DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const 
              float* q, float* k, float* v, float* ao, float* sc)
 {
     lin_qkv<NS>(q, xq, Tq, xkv, Tk, w + in_wT, w + in_b);
+    STAMP(1);
     attention<NS>(ao, q, k, v, sc, Tq, Tk);
+    STAMP(2);
     lin<D / 4, NS>(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
+    STAMP(3);
 }
+
+// ---- the TEAM exchange (few sequences: G workgroups run one sequence's block together, below) -------------------------------------------
+// Unit of exchange: a 16-byte GRANULE = three partial sums + a tag, written with ONE write-through store (`sc1`: the bytes leave the
+// writer's XCD) and read with `sc1` loads (never served by the reader's L1): the tag arrives with its data, so there is no flag, no
+// drain and no fence -- a reader re-reads the G granules of its three outputs until all carry the tag of this exchange.  Granule i of the
+// G workgroups is contiguous ([granule][workgroup]): one address register, immediate offsets.
+constexpr int XCH_GRANULES = 2 * 16 * D / 3;          // two token tiles of 16 x 48 partial sums, three per granule
+constexpr int XCH_POLL_LIMIT = 1 << 19;               // (~1 s: then the team gives up, sets the handle's status word and finishes with garbage)
+DEV void store_granule(f4* p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+template <int N> DEV void load_granules(f4 (&v)[16], const f4* p);
+template <> DEV void load_granules<2>(f4 (&v)[16], const f4* p)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(p) : "memory");
+}
+template <> DEV void load_granules<4>(f4 (&v)[16], const f4* p)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
+}
+template <> DEV void load_granules<8>(f4 (&v)[16], const f4* p)
+{
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:112 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(p) : "memory");
+}
+template <> DEV void load_granules<16>(f4 (&v)[16], const f4* p)
+{
+    asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %16, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %16, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:80 sc1\n\t"
+                 "global_load_dwordx4 %6, %16, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:112 sc1\n\t"
+                 "global_load_dwordx4 %8, %16, off offset:128 sc1\n\tglobal_load_dwordx4 %9, %16, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %10, %16, off offset:160 sc1\n\tglobal_load_dwordx4 %11, %16, off offset:176 sc1\n\t"
+                 "global_load_dwordx4 %12, %16, off offset:192 sc1\n\tglobal_load_dwordx4 %13, %16, off offset:208 sc1\n\t"
+                 "global_load_dwordx4 %14, %16, off offset:224 sc1\n\tglobal_load_dwordx4 %15, %16, off offset:240 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]),
+                   "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                 : "v"(p) : "memory");
+}
+struct Team { // (uniform per workgroup)
+    f4* xch;       // this team's exchange area: [2 slots][XCH_GRANULES][G] granules
+    int* status;   // the handle's status word
+    unsigned tag;  // tag of the NEXT exchange (counts up: every workgroup of a team makes the same calls in the same order)
+    int g, G;      // this workgroup's rank in its team, the team's size (2, 4, 8 or 16)
+    int* dead;     // (LDS) an exchange of this workgroup has timed out: no further waiting
+};
 
 // one tile of 16 hidden units: H^T = W1 X^T (12 MFMAs), bias + ReLU, OUT += H W2^T (12 MFMAs; the first product's
 // accumulator is the second's A operand)
@@ -338,8 +410,11 @@ DEV void ffn_load(f4 (&im)[7], const f4* img, int nt, int ntiles)
 // PREFETCH: a wave keeps the images of three tiles in flight (84 registers: the one-workgroup-per-CU kernel, where a SIMD
 // has two waves to hide an L2 round trip behind 768 cycles of MFMA per tile); otherwise one, and four waves per SIMD.
 // NS = 2: every tile image serves the token tiles of both sequences.
-template <bool PREFETCH, int NS, int R = 16>
-DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red)
+// TEAM (NS = 1): workgroup g of G takes the tiles g * 8 + wave, + 8 G, ...; its eight waves' partial outputs are summed through LDS as ever, the G
+// workgroups' sums are exchanged as granules (above) and every workgroup adds them up in the same order -- all G hold the same `o` afterwards,
+// bit for bit, which is what lets them run the rest of the block redundantly and in step.
+template <bool PREFETCH, int NS, int R = 16, bool TEAM = false>
+DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red, Team* tm = nullptr)
 { // (R, the rows per sequence, is a compile-time constant here: as a run-time value it cost the 128-register instantiation 8 spills)
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
@@ -348,6 +423,9 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
     const f4* img = (const f4*)(w + pack) + lane;
     constexpr int NG = NS == 1 ? 1 : (NS * R + 15) / 16; // token tiles that share one pass over the weights (R = 8: ONE tile for the two sequences)
     const int ntt = n_ttiles<NS>(T, R);
+    const int first = TEAM ? tm->g * NWV + wave : wave, stride = TEAM ? tm->G * NWV : NWV; // this wave's tiles
+    f4* xslot = nullptr;
+    if (TEAM) xslot = tm->xch + (size_t)(tm->tag & 1u) * XCH_GRANULES * tm->G;
 #pragma unroll 1
     for (int tt0 = 0; tt0 < ntt; tt0 += NG) {
         constexpr int ng = NG;
@@ -363,28 +441,28 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
         }
         if (PREFETCH) {
             f4 b0[7], b1[7], b2[7];
-            int nt = wave;
+            int nt = first;
             ffn_load(b0, img, nt, ntiles);
-            ffn_load(b1, img, nt + NWV, ntiles);
+            ffn_load(b1, img, nt + stride, ntiles);
             while (nt < ntiles) {
-                ffn_load(b2, img, nt + 2 * NWV, ntiles);
+                ffn_load(b2, img, nt + 2 * stride, ntiles);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b0, xb[g], acc[g]);
-                nt += NWV;
+                nt += stride;
                 if (nt >= ntiles) break;
-                ffn_load(b0, img, nt + 2 * NWV, ntiles);
+                ffn_load(b0, img, nt + 2 * stride, ntiles);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b1, xb[g], acc[g]);
-                nt += NWV;
+                nt += stride;
                 if (nt >= ntiles) break;
-                ffn_load(b1, img, nt + 2 * NWV, ntiles);
+                ffn_load(b1, img, nt + 2 * stride, ntiles);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b2, xb[g], acc[g]);
-                nt += NWV;
+                nt += stride;
             }
         } else {
 #pragma unroll 1
-            for (int nt = wave; nt < ntiles; nt += NWV) {
+            for (int nt = first; nt < ntiles; nt += stride) {
                 f4 cur[7];
                 ffn_load(cur, img, nt, ntiles);
 #pragma unroll
@@ -400,6 +478,24 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) *(f4*)(red + ((wave * 3 + ct) * 64 + lane) * 4) = acc[g][ct];
             __syncthreads();
+            if (TEAM) { // this workgroup's sums of token tile tt leave as granules: thread i < 256 = outputs 3 i .. 3 i + 2 (one row: 48 = 16 x 3)
+                const int i = threadIdx.x, tl = i >> 4, c0 = 3 * (i & 15);
+                if (i < 16 * D / 3 && row_valid<NS>(16 * tt + tl, T, R)) {
+                    f4 gr;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int c = c0 + j, slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
+                        float sum = 0.f;
+#pragma unroll
+                        for (int wv = 0; wv < NWV; ++wv) sum += red[wv * 3 * 256 + slot];
+                        gr[j] = sum;
+                    }
+                    gr[3] = __uint_as_float(tm->tag);
+                    store_granule(xslot + (size_t)(tt * (16 * D / 3) + i) * tm->G + tm->g, gr);
+                }
+                __syncthreads();
+                continue;
+            }
             for (int idx = threadIdx.x; idx < 16 * D; idx += NT) {
                 const int tl = idx / D, c = idx - tl * D;
                 if (row_valid<NS>(16 * tt + tl, T, R)) {
@@ -413,13 +509,46 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
             __syncthreads();
         }
     }
+    if (TEAM) { // gather: thread i = granule i of the (at most two) token tiles; the G workgroups' granules of it are G x 16 contiguous bytes
+        const int i = threadIdx.x, tt = i >> 8, il = i & 255, tl = il >> 4, c0 = 3 * (il & 15);
+        if (tt < ntt && row_valid<NS>(16 * tt + tl, T, R)) {
+            const f4* src = xslot + (size_t)i * tm->G;
+            f4 v[16];
+            const int G = tm->G;
+            const bool dead = *tm->dead != 0;
+            for (int tries = 0;;) {
+                if (G == 16) load_granules<16>(v, src);
+                else if (G == 8) load_granules<8>(v, src);
+                else if (G == 4) load_granules<4>(v, src);
+                else load_granules<2>(v, src);
+                bool all = true;
+#pragma unroll
+                for (int gg = 0; gg < 16; ++gg) if (gg < G) all = all && __float_as_uint(v[gg][3]) == tm->tag;
+                if (all || dead) break;
+                if (++tries >= XCH_POLL_LIMIT) { *tm->status = 1; *tm->dead = 1; break; } // (gives up: on with what is there, no further waiting)
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float sum = w[l2b + c0 + j];
+#pragma unroll
+                for (int gg = 0; gg < 16; ++gg) if (gg < G) sum += v[gg][j];
+                o[(16 * tt + tl) * D + c0 + j] = sum;
+            }
+        }
+        __syncthreads();
+        tm->tag += 1u;
+    }
 }
 
 // OCC = waves per SIMD: 4 (two workgroups per CU, 128 registers: throughput with many sequences) or 2 (one workgroup per CU,
 // 256 registers, feed-forward weights prefetched three tiles deep: latency with few).  NS = sequences per workgroup.
-template <int OCC, int NS>
+// TEAM (OCC = 2, NS = 1; few sequences): a.G workgroups per sequence.  Every one of them runs the whole block -- same instructions, same data, same
+// bits -- except the feed-forward layers (94 % of the work), where each takes 1/G of the hidden units and the partial sums are exchanged (ffn).
+template <int OCC, int NS, bool TEAM = false>
 __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
 {
+    static_assert(!TEAM || NS == 1, "a team runs one sequence");
     __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D];
     // q, k, v and the attention output; dead while the feed-forward block runs, whose cross-wave reduction buffer is the
     // same 24 KB (70 KB of LDS in all: two workgroups per CU)
@@ -427,9 +556,18 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     static_assert(4 * MAXT * D >= NWV * 3 * 64 * 4, "the reduction buffer fits the attention buffers");
     float *q = qkva, *kb = qkva + MAXT * D, *vb = qkva + 2 * MAXT * D, *ao = qkva + 3 * MAXT * D, *red = qkva;
     __shared__ float sc[NHD * MAXT * MAXT], tok[MAXT * LAT], enc_in[MAXT * MAX_IN], preds[NS * (MAXT + 1) * LAT];
-    const int s0 = blockIdx.x * NS, tid = threadIdx.x;
+    const int s0 = TEAM ? (int)blockIdx.x / a.G : (int)blockIdx.x * NS, tid = threadIdx.x;
     if (s0 >= a.n_seq) return;
+    __shared__ int team_dead;
+    Team team{};
+    if (TEAM) {
+        team.g = (int)blockIdx.x - s0 * a.G; team.G = a.G;
+        team.xch = (f4*)a.xch + (size_t)s0 * 2 * XCH_GRANULES * a.G;
+        team.status = a.tstatus; team.tag = a.epoch0 + 1u; team.dead = &team_dead;
+        if (tid == 0) team_dead = 0; // (read after the barriers below)
+    }
     const float* w = a.w;
+    STAMP(0);
     const int H = a.H, step = a.step, n_past = (H + step - 1) / step, Te = n_past - 1, n_steps = a.window / step + 1;
 
     // ---- tokens (drag_pose.py:249-266): latent normalised | displacement accumulated over `step` frames | heights.
@@ -452,20 +590,27 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         tok[16 * sl * LAT + c] = s < a.n_seq ? (a.latent_buf[((size_t)s * H + Te * step) * LAT + c] - w[a.mean + c]) / w[a.stdv + c] : 0.f;
     }
     __syncthreads();
+    STAMP(10);
 
     // ---- encoder, once (the memory is the same for every autoregressive call)
     lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
+    STAMP(11);
     for (int l = 0; l < a.n_enc; ++l) {
         const TLayer L = ((const TLayer*)(w + a.enc_tab))[l];
         mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln<NS>(x, o, Te, w + L.n1w, w + L.n1b);
-        if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform; a history of at most 8 tokens)
+        STAMP(4);
+        if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, &team);
+        else if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform; a history of at most 8 tokens)
         else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
+        STAMP(5);
         add_ln<NS>(x, o, Te, w + L.n2w, w + L.n2b);
+        STAMP(4);
     }
     add_ln<NS>(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
     for (int idx = tid; idx < MAXT * D; idx += NT) mem[idx] = x[idx];
     __syncthreads();
+    STAMP(12);
 
     // ---- autoregressive calls (drag_pose.py:274-279): call i sees i + 1 target tokens, keeps the last position's output
     for (int it = 0; it < n_steps; ++it) {
@@ -473,28 +618,38 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         // (the activations of a call over at most 8 tokens take 8 rows per sequence: two sequences share a tile -- rows_per_seq; the token buffer
         //  keeps 16, the memory the layout of its own token count)
         lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe, 16);
+        STAMP(13);
         for (int l = 0; l < a.n_dec; ++l) {
             const TLayer L = ((const TLayer*)(w + a.dec_tab))[l];
             mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, w + L.n1w, w + L.n1b);
+            STAMP(4);
             mha<NS>(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, w + L.n2w, w + L.n2b);
-            if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform)
+            STAMP(4);
+            if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, &team);
+            else if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform)
             else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
+            STAMP(5);
             add_ln<NS>(x, o, T, w + L.n3w, w + L.n3b);
+            STAMP(4);
         }
         add_ln<NS>(x, nullptr, T, w + a.decn_w, w + a.decn_b);
+        STAMP(4);
         next_token<NS>(tok, preds, x, T, it, it + 1 < n_steps, w + a.op_wT, w + a.op_b);
+        STAMP(14);
     }
 
     // ---- de-normalise, then the reference's "lerp" with weight 1 (drag_pose.py:283-291): frame k of the window holds the
     //      NEXT sampled prediction, the last frame its own
     const int W = a.window;
+    if (TEAM && team.g != 0) return; // (every workgroup of the team holds the result; the first stores it)
     for (int idx = tid; idx < NS * (W + 1) * LAT; idx += NT) {
         const int sl = idx / ((W + 1) * LAT), r2 = idx - sl * (W + 1) * LAT, k = r2 / LAT, c = r2 - k * LAT, m = k < W ? k / step + 1 : W / step;
         if (s0 + sl < a.n_seq)
             a.target[((size_t)(s0 + sl) * (W + 1) + k) * LAT + c] = preds[(sl * (MAXT + 1) + m) * LAT + c] * w[a.stdv + c] + w[a.mean + c];
     }
+    STAMP(15);
 }
 
 thread_local std::string g_terr;
@@ -506,6 +661,8 @@ struct dp_temporal {
     int forced_variant = 0; // dp_temporal_debug_force_variant (private test hook, below): 21, 41 or 42 (waves per SIMD, sequences
                             // per workgroup) = that kernel variant whatever the batch; 0 = chosen from the batch (the product)
     float* d_w = nullptr;
+    float* d_xch = nullptr;  // the teams' exchange area (n_cu workgroups' worth of granules) + the status word behind it
+    unsigned epoch = 0;      // tag of the last exchange any launch has made (tags never repeat within the handle's life: below)
     TArgs args{};
     std::string err;
 };
@@ -622,9 +779,13 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->n_cu = cu; }
     hipError_t e = hipMalloc((void**)&t->d_w, buf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->d_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice);
+    const size_t xch_bytes = (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4) + 16;
+    if (e == hipSuccess) e = hipMalloc((void**)&t->d_xch, xch_bytes);
+    if (e == hipSuccess) e = hipMemset(t->d_xch, 0, xch_bytes); // (tag 0 = never written; the first exchange carries tag 1)
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         if (t->d_w) (void)hipFree(t->d_w);
+        if (t->d_xch) (void)hipFree(t->d_xch);
         delete t;
         return tfail(nullptr, DP_ERR_DEVICE, std::string("dp_temporal_create: ") + hipGetErrorString(e));
     }
@@ -641,17 +802,44 @@ extern "C" int dp_temporal_destroy(dp_temporal* t)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(t->device);
     if (t->d_w) (void)hipFree(t->d_w);
+    if (t->d_xch) (void)hipFree(t->d_xch);
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
     delete t;
     return DP_OK;
 }
 
+#ifdef DPT_STAMPS
+// diagnostic build only: the stamps of the launches since the last call (synchronises the device)
+extern "C" int dp_temporal_debug_read_stamps(unsigned long long* out, int cap)
+{
+    int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_nstamps), sizeof(int)) != hipSuccess) return -1;
+    n = n < cap ? n : cap;
+    if (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+    const int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nstamps), &zero, sizeof(int)) != hipSuccess) return -1;
+    return n;
+}
+#endif
+
 // private test hook (not in include/dragposer.h; the product reads no environment variable): pin the kernel variant of later predictions
 extern "C" int dp_temporal_debug_force_variant(dp_temporal* t, int variant)
 {
-    if (!t || (variant != 0 && variant != 21 && variant != 41 && variant != 42)) return DP_ERR_INVALID;
+    // (102, 104, 108, 116: a team of 2 / 4 / 8 / 16 workgroups per sequence where the launch fits the device, else as 0)
+    if (!t || (variant != 0 && variant != 21 && variant != 41 && variant != 42 && variant != 102 && variant != 104 && variant != 108 && variant != 116)) return DP_ERR_INVALID;
     t->forced_variant = variant;
     return DP_OK;
+}
+
+// private test hook: the teams' status word (0: every exchange completed; 1: a workgroup waited XCH_POLL_LIMIT reads for its team -- the launch's
+// predictions are garbage); synchronises the device
+extern "C" int dp_temporal_debug_team_status(dp_temporal* t)
+{
+    if (!t || !t->d_xch) return -1;
+    int v = -1;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&v, (char*)t->d_xch + (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
 }
 
 extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state* st, int window, float* target_buf, void* stream)
@@ -675,8 +863,24 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     // workgroup when each has at most 16 tokens (every weight fetch then serves both)
     const bool pair_ok = n_past - 1 <= 16 && n_steps <= 16;
     int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? 42 : 41);
+    // few sequences: a TEAM of G workgroups per sequence (the largest power of two up to 16 with every workgroup on a CU of its own -- they wait for
+    // each other, so all of them must be resident -- and at least one feed-forward tile per wave)
+    int G = 1;
+    while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + 15) / 16 >= 2 * G * NWV) G *= 2;
+    if (t->forced_variant >= 100) { const int want = t->forced_variant - 100; G = G >= want ? want : 1; }
+    if (G >= 2 && (t->forced_variant == 0 || t->forced_variant >= 100)) variant = 100 + G;
     if (t->forced_variant == 21 || t->forced_variant == 41 || (t->forced_variant == 42 && pair_ok)) variant = t->forced_variant;
-    if (variant == 21) hipLaunchKernelGGL((dp_temporal_kernel<2, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    if (variant >= 100) {
+        const unsigned calls = (unsigned)(m.n_enc + n_steps * m.n_dec); // exchanges of this launch: tags epoch + 1 ... epoch + calls
+        if (t->epoch > 0xFFFF0000u - calls) { // (32-bit tags: start over on a clean area, once per 4 G exchanges)
+            if (hipMemsetAsync(t->d_xch, 0, (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4), (hipStream_t)stream) != hipSuccess)
+                return tfail(t, DP_ERR_DEVICE, "dp_temporal_predict: cannot reset the exchange area");
+            t->epoch = 0;
+        }
+        a.G = G; a.xch = t->d_xch; a.tstatus = (int*)((char*)t->d_xch + (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4)); a.epoch0 = t->epoch;
+        t->epoch += calls;
+        hipLaunchKernelGGL((dp_temporal_kernel<2, 1, true>), dim3(n_seq * G), dim3(NT), 0, (hipStream_t)stream, a);
+    } else if (variant == 21) hipLaunchKernelGGL((dp_temporal_kernel<2, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
     else if (variant == 41) hipLaunchKernelGGL((dp_temporal_kernel<4, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dp_temporal_kernel<4, 2>), dim3((n_seq + 1) / 2), dim3(NT), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();

@@ -132,10 +132,15 @@ class NativeTemporal:
         self._h = h
 
     def _force_variant(self, variant):
-        """tests only: pin the kernel variant (21 / 41 / 42: waves per SIMD, sequences per workgroup; 0: chosen from the batch)"""
+        """tests only: pin the kernel variant (21 / 41 / 42: waves per SIMD, sequences per workgroup; 102 / 104 / 108 / 116: a team of that many
+        workgroups per sequence; 0: chosen from the batch)"""
         rc = self._lib.dp_temporal_debug_force_variant(self._h, int(variant))
         if rc != 0:
             raise ValueError(f"dp_temporal_debug_force_variant({variant}) -> {rc}")
+
+    def _team_status(self):
+        """tests only (synchronises): 0 = every exchange between the workgroups of a team has completed"""
+        return int(self._lib.dp_temporal_debug_team_status(self._h))
 
     def predict(self, latent_buffer, displacement_buffer, heights_buffer, window, out=None):
         """history buffers [S, H, 24] / [S, H, 3] / [S, H, n_heights] (fp32, on the device, newest entry last)

@@ -37,7 +37,8 @@ def _torch_block(model, means, stds, lat, disp, hts, window):
 
 # the kernel variants (waves per SIMD, sequences per workgroup): 21 = one workgroup per CU with prefetch (few sequences),
 # 41 = two workgroups per CU, 42 = two per CU with two sequences each (many sequences of at most 16 tokens)
-@pytest.mark.parametrize("variant", [21, 41, 42])
+# 102 ... 116: a TEAM of 2 ... 16 workgroups per sequence (what few sequences get: each takes 1 / G of every feed-forward layer)
+@pytest.mark.parametrize("variant", [21, 41, 42, 102, 104, 108, 116])
 @pytest.mark.parametrize("window", [0, 16, 60])
 def test_native_predictor_matches_nn_transformer_at_full_size(window, variant):
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
@@ -57,6 +58,10 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window, variant):
     nat._force_variant(variant)  # (private test hook: dp_temporal_debug_force_variant)
     got = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
     assert got.shape == (S, window + 1, 24)
+    assert nat._team_status() == 0
+    if variant >= 100:  # launch after launch over the same exchange area (tags count on), and what the library picks by itself
+        again = nat.predict(lat.cuda(), disp.cuda(), hts.cuda(), window).cpu()
+        assert torch.equal(again, got) and nat._team_status() == 0
     err = (got - want).abs().max().item()
     print(f"window {window}, variant {variant}: max |native - nn.Transformer| = {err:.2e} (targets of magnitude {want.abs().max().item():.2f})")
     # fp32 against fp32 in a different summation order through 6 LayerNorm-ed layers and up to 16 autoregressive calls
