@@ -48,8 +48,8 @@ struct TArgs {
     int H, n_seq, window;
     // a TEAM of G workgroups per sequence (few sequences: latency; below): the exchange area of the handle, the tag base of this launch
     float* xch;
+    unsigned* epochs; // one word per team: the tag of the team's last exchange (device-resident, so that a captured launch can be replayed)
     int* tstatus;
-    unsigned epoch0;
     int G;
 };
 
@@ -219,6 +219,7 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
         const float r = 1.f / sqrtf(wave_sum(d * d) * (1.f / D) + 1e-5f);
         if (live) x[t * D + lane] = d * r * gc + bc;
     }
+    STAMP(25);
     __syncthreads();
 }
 
@@ -260,20 +261,25 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
             if (row_valid<NS>(g, Tj, Rj)) out[g * D] = acc0[r] + acc1[r] + bias;
         }
     }
+    STAMP(22);
     __syncthreads();
 }
 
-// multi-head attention of Tq queries over Tk <= 32 keys (no mask), one wave per (sequence, head), one phase:
+// multi-head attention of Tq queries over Tk <= 32 keys (no mask), one phase:
 //   ao[i][h*HD + c] = sum_j softmax_j(q_i . k_j / sqrt(HD)) v[j][h*HD + c]
+// NS = 2: one wave per (sequence, head).  NS = 1: TWO waves per head, each with every other turn of four queries.
 // Lane (row r, j) -- r = lane / 16, j = lane % 16 -- holds keys j and j + 16; a turn of the loop takes four queries, one per
 // DPP row: 12-term dot products, the maximum and the sum over the keys by row reductions in registers, the probabilities
-// through the wave's score rows in LDS (same wave: no barrier); then lane (query, channel) accumulates the output.
+// through the wave's score rows in LDS (same wave: no barrier); then lane (query of the turn, channel) accumulates the output --
+// the keys in their order, eight probabilities and values requested at a time (one LDS round trip per eight keys, not per key).
 template <int NS>
 DEV void attention(float* ao, const float* q, const float* k, const float* v, float* sc, int Tq, int Tk)
 {
     const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = wave & (NHD - 1), sq = wave / NHD; // NS = 1: waves 0..3, one per head; NS = 2: wave = 4 * sequence + head
+    const int h = wave & (NHD - 1), sq = NS == 1 ? 0 : wave / NHD; // NS = 1: waves h and h + 4 share head h; NS = 2: wave = 4 * sequence + head
+    constexpr int SHARE = NS == 1 ? NWV / NHD : 1;                  // waves per (sequence, head)
+    const int part = NS == 1 ? wave / NHD : 0;
     if (sq < NS) {
         q += Rq * sq * D; k += Rk * sq * D; v += Rk * sq * D; ao += Rq * sq * D; // (the sequence's rows)
         const float scale = 1.f / sqrtf((float)HD);
@@ -285,9 +291,11 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
             k0[c] = live0 ? k[j * D + h * HD + c] : 0.f;
             k1[c] = live1 ? k[(j + 16) * D + h * HD + c] : 0.f;
         }
+        STAMP(20);
         float* sch = sc + (NS == 1 ? h * MAXT * MAXT : wave * 16 * MAXT);
+        const int iq = lane / HD, cq = lane - iq * HD; // second half of a turn: lane (query iq of the turn, channel cq), lanes 0 .. 47
 #pragma unroll 1
-        for (int i0 = 0; i0 < Tq; i0 += 4) {
+        for (int i0 = 4 * part; i0 < Tq; i0 += 4 * SHARE) {
             const int i = min(i0 + r, Tq - 1); // (a row beyond the last query recomputes it)
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -303,15 +311,28 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
             const float inv = 1.f / row_sum(e0 + e1);
             if (live0) sch[i * MAXT + j] = e0 * inv;
             if (live1) sch[i * MAXT + j + 16] = e1 * inv;
+            // (LDS operations of a wave execute in order: the probabilities written above are visible below)
+            const int io = i0 + iq;
+            if (iq < 4 && io < Tq) {
+                const float* p = sch + io * MAXT;
+                const float* vc = v + h * HD + cq;
+                float acc = 0.f;
+#pragma unroll 1
+                for (int j0 = 0; j0 < Tk; j0 += 8) {
+                    float pj[8], vj[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = j0 + u < Tk;
+                        pj[u] = in ? p[j0 + u] : 0.f;
+                        vj[u] = in ? vc[(j0 + u) * D] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = fmaf(pj[u], vj[u], acc); // (a key beyond the last adds 0 * 0: nothing)
+                }
+                ao[io * D + h * HD + cq] = acc;
+            }
         }
-        // (LDS operations of a wave execute in order: the probabilities written above are visible below)
-        for (int idx = lane; idx < Tq * HD; idx += 64) {
-            const int i = idx / HD, c = idx - i * HD;
-            const float* p = sch + i * MAXT;
-            float acc = 0.f;
-            for (int jj = 0; jj < Tk; ++jj) acc = fmaf(p[jj], v[jj * D + h * HD + c], acc);
-            ao[i * D + h * HD + c] = acc;
-        }
+        STAMP(21);
     }
     __syncthreads();
 }
@@ -334,7 +355,12 @@ DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const 
 // writer's XCD) and read with `sc1` loads (never served by the reader's L1): the tag arrives with its data, so there is no flag, no
 // drain and no fence -- a reader re-reads the G granules of its three outputs until all carry the tag of this exchange.  Granule i of the
 // G workgroups is contiguous ([granule][workgroup]): one address register, immediate offsets.
+// Tags: every team counts its exchanges in a word of device memory that lives as long as the handle (read by all its workgroups at entry, written
+// back by the first at exit -- which it reaches only after every member has entered); a slot (team, granule, member) is only ever written by that
+// member of that team, whatever the team size of the launch (the layout is that of the largest team), so what a slot holds is always an OLDER tag of
+// the same counter: never the awaited one.  Nothing of this lives in kernel arguments: a launch captured into a graph can be replayed.
 constexpr int XCH_GRANULES = 2 * 16 * D / 3;          // two token tiles of 16 x 48 partial sums, three per granule
+constexpr int XCH_GMAX = 16;                          // the largest team; slots per granule in the layout
 constexpr int XCH_POLL_LIMIT = 1 << 19;               // (~1 s: then the team gives up, sets the handle's status word and finishes with garbage)
 DEV void store_granule(f4* p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 template <int N> DEV void load_granules(f4 (&v)[16], const f4* p);
@@ -372,7 +398,7 @@ template <> DEV void load_granules<16>(f4 (&v)[16], const f4* p)
                  : "v"(p) : "memory");
 }
 struct Team { // (uniform per workgroup)
-    f4* xch;       // this team's exchange area: [2 slots][XCH_GRANULES][G] granules
+    f4* xch;       // this team's exchange area: [2 slots][XCH_GRANULES][XCH_GMAX] granules
     int* status;   // the handle's status word
     unsigned tag;  // tag of the NEXT exchange (counts up: every workgroup of a team makes the same calls in the same order)
     int g, G;      // this workgroup's rank in its team, the team's size (2, 4, 8 or 16)
@@ -414,8 +440,8 @@ DEV void ffn_load(f4 (&im)[7], const f4* img, int nt, int ntiles)
 // workgroups' sums are exchanged as granules (above) and every workgroup adds them up in the same order -- all G hold the same `o` afterwards,
 // bit for bit, which is what lets them run the rest of the block redundantly and in step.
 template <bool PREFETCH, int NS, int R = 16, bool TEAM = false>
-DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red, Team* tm = nullptr)
-{ // (R, the rows per sequence, is a compile-time constant here: as a run-time value it cost the 128-register instantiation 8 spills)
+DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red, Team* tm = nullptr, const f4 (*pre)[7] = nullptr)
+{ // (pre: TEAM -- the image of this wave's first tile, requested by the caller at the head of the layer: a cold fetch hidden behind the attention) // (R, the rows per sequence, is a compile-time constant here: as a run-time value it cost the 128-register instantiation 8 spills)
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
     const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
@@ -425,7 +451,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
     const int ntt = n_ttiles<NS>(T, R);
     const int first = TEAM ? tm->g * NWV + wave : wave, stride = TEAM ? tm->G * NWV : NWV; // this wave's tiles
     f4* xslot = nullptr;
-    if (TEAM) xslot = tm->xch + (size_t)(tm->tag & 1u) * XCH_GRANULES * tm->G;
+    if (TEAM) xslot = tm->xch + (size_t)(tm->tag & 1u) * XCH_GRANULES * XCH_GMAX;
 #pragma unroll 1
     for (int tt0 = 0; tt0 < ntt; tt0 += NG) {
         constexpr int ng = NG;
@@ -439,7 +465,23 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
         }
-        if (PREFETCH) {
+        if (TEAM) { // (at most 16 / G tiles per wave: two images in flight, the first one requested by the caller)
+            f4 b0[7], b1[7];
+            int nt = first;
+            if (pre) {
+#pragma unroll
+                for (int v = 0; v < 7; ++v) b0[v] = (*pre)[v];
+            } else ffn_load(b0, img, nt, ntiles);
+            while (nt < ntiles) {
+                ffn_load(b1, img, nt + stride, ntiles);
+                ffn_tile(b0, xb[0], acc[0]);
+                nt += stride;
+                if (nt >= ntiles) break;
+                ffn_load(b0, img, nt + stride, ntiles);
+                ffn_tile(b1, xb[0], acc[0]);
+                nt += stride;
+            }
+        } else if (PREFETCH) {
             f4 b0[7], b1[7], b2[7];
             int nt = first;
             ffn_load(b0, img, nt, ntiles);
@@ -469,6 +511,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
                 for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(cur, xb[g], acc[g]);
             }
         }
+        STAMP(23);
         // the waves' partial outputs, one token tile at a time through the reduction buffer: lane (channel l16 of tile ct,
         // token group q), register r = token 4 q + r
 #pragma unroll
@@ -491,7 +534,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
                         gr[j] = sum;
                     }
                     gr[3] = __uint_as_float(tm->tag);
-                    store_granule(xslot + (size_t)(tt * (16 * D / 3) + i) * tm->G + tm->g, gr);
+                    store_granule(xslot + (size_t)(tt * (16 * D / 3) + i) * XCH_GMAX + tm->g, gr);
                 }
                 __syncthreads();
                 continue;
@@ -509,10 +552,11 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
             __syncthreads();
         }
     }
+    STAMP(24);
     if (TEAM) { // gather: thread i = granule i of the (at most two) token tiles; the G workgroups' granules of it are G x 16 contiguous bytes
         const int i = threadIdx.x, tt = i >> 8, il = i & 255, tl = il >> 4, c0 = 3 * (il & 15);
         if (tt < ntt && row_valid<NS>(16 * tt + tl, T, R)) {
-            const f4* src = xslot + (size_t)i * tm->G;
+            const f4* src = xslot + (size_t)i * XCH_GMAX;
             f4 v[16];
             const int G = tm->G;
             const bool dead = *tm->dead != 0;
@@ -562,12 +606,13 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     Team team{};
     if (TEAM) {
         team.g = (int)blockIdx.x - s0 * a.G; team.G = a.G;
-        team.xch = (f4*)a.xch + (size_t)s0 * 2 * XCH_GRANULES * a.G;
-        team.status = a.tstatus; team.tag = a.epoch0 + 1u; team.dead = &team_dead;
+        team.xch = (f4*)a.xch + (size_t)s0 * 2 * XCH_GRANULES * XCH_GMAX;
+        team.status = a.tstatus; team.tag = a.epochs[s0] + 1u; team.dead = &team_dead;
         if (tid == 0) team_dead = 0; // (read after the barriers below)
     }
     const float* w = a.w;
     STAMP(0);
+    const TLayer* tab = (const TLayer*)(w + a.enc_tab); // (encoder layers, then decoder layers: one table)
     const int H = a.H, step = a.step, n_past = (H + step - 1) / step, Te = n_past - 1, n_steps = a.window / step + 1;
 
     // ---- tokens (drag_pose.py:249-266): latent normalised | displacement accumulated over `step` frames | heights.
@@ -596,11 +641,13 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
     STAMP(11);
     for (int l = 0; l < a.n_enc; ++l) {
-        const TLayer L = ((const TLayer*)(w + a.enc_tab))[l];
+        const TLayer L = tab[l];
+        f4 pre[7];
+        if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
         mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln<NS>(x, o, Te, w + L.n1w, w + L.n1b);
         STAMP(4);
-        if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, &team);
+        if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, &team, &pre);
         else if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform; a history of at most 8 tokens)
         else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
         STAMP(5);
@@ -620,14 +667,16 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe, 16);
         STAMP(13);
         for (int l = 0; l < a.n_dec; ++l) {
-            const TLayer L = ((const TLayer*)(w + a.dec_tab))[l];
+            const TLayer L = tab[a.n_enc + l];
+            f4 pre[7];
+            if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
             mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, w + L.n1w, w + L.n1b);
             STAMP(4);
             mha<NS>(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, w + L.n2w, w + L.n2b);
             STAMP(4);
-            if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, &team);
+            if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, &team, &pre);
             else if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform)
             else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
             STAMP(5);
@@ -644,6 +693,7 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     //      NEXT sampled prediction, the last frame its own
     const int W = a.window;
     if (TEAM && team.g != 0) return; // (every workgroup of the team holds the result; the first stores it)
+    if (TEAM && tid == 0) a.epochs[s0] = team.tag - 1u; // (the team's last tag: every member has read the word long ago -- it has published since)
     for (int idx = tid; idx < NS * (W + 1) * LAT; idx += NT) {
         const int sl = idx / ((W + 1) * LAT), r2 = idx - sl * (W + 1) * LAT, k = r2 / LAT, c = r2 - k * LAT, m = k < W ? k / step + 1 : W / step;
         if (s0 + sl < a.n_seq)
@@ -661,8 +711,8 @@ struct dp_temporal {
     int forced_variant = 0; // dp_temporal_debug_force_variant (private test hook, below): 21, 41 or 42 (waves per SIMD, sequences
                             // per workgroup) = that kernel variant whatever the batch; 0 = chosen from the batch (the product)
     float* d_w = nullptr;
-    float* d_xch = nullptr;  // the teams' exchange area (n_cu workgroups' worth of granules) + the status word behind it
-    unsigned epoch = 0;      // tag of the last exchange any launch has made (tags never repeat within the handle's life: below)
+    float* d_xch = nullptr;  // the teams' exchange area: [n_cu / 2 teams][2][XCH_GRANULES][XCH_GMAX] granules, the teams' tag counters, the status word
+    size_t xch_granule_bytes = 0;
     TArgs args{};
     std::string err;
 };
@@ -779,9 +829,11 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->n_cu = cu; }
     hipError_t e = hipMalloc((void**)&t->d_w, buf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->d_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice);
-    const size_t xch_bytes = (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4) + 16;
+    const int max_teams = t->n_cu / 2 > 0 ? t->n_cu / 2 : 1;
+    t->xch_granule_bytes = (size_t)max_teams * 2 * XCH_GRANULES * XCH_GMAX * sizeof(f4);
+    const size_t xch_bytes = t->xch_granule_bytes + (size_t)max_teams * sizeof(unsigned) + 16;
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_xch, xch_bytes);
-    if (e == hipSuccess) e = hipMemset(t->d_xch, 0, xch_bytes); // (tag 0 = never written; the first exchange carries tag 1)
+    if (e == hipSuccess) e = hipMemset(t->d_xch, 0, xch_bytes); // (tag 0 = never written; a team's first exchange carries tag 1)
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         if (t->d_w) (void)hipFree(t->d_w);
@@ -838,7 +890,7 @@ extern "C" int dp_temporal_debug_team_status(dp_temporal* t)
     if (!t || !t->d_xch) return -1;
     int v = -1;
     if (hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpy(&v, (char*)t->d_xch + (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        hipMemcpy(&v, (char*)t->d_xch + t->xch_granule_bytes + (size_t)(t->n_cu / 2 > 0 ? t->n_cu / 2 : 1) * sizeof(unsigned), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
 }
 
@@ -867,18 +919,13 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     // each other, so all of them must be resident -- and at least one feed-forward tile per wave)
     int G = 1;
     while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + 15) / 16 >= 2 * G * NWV) G *= 2;
+    if (G == 16 && n_seq * 64 > t->n_cu && t->forced_variant < 100) G = 8; // (16 pays with a quarter of the device at most: profiles/r05_team_latency.txt)
     if (t->forced_variant >= 100) { const int want = t->forced_variant - 100; G = G >= want ? want : 1; }
     if (G >= 2 && (t->forced_variant == 0 || t->forced_variant >= 100)) variant = 100 + G;
     if (t->forced_variant == 21 || t->forced_variant == 41 || (t->forced_variant == 42 && pair_ok)) variant = t->forced_variant;
     if (variant >= 100) {
-        const unsigned calls = (unsigned)(m.n_enc + n_steps * m.n_dec); // exchanges of this launch: tags epoch + 1 ... epoch + calls
-        if (t->epoch > 0xFFFF0000u - calls) { // (32-bit tags: start over on a clean area, once per 4 G exchanges)
-            if (hipMemsetAsync(t->d_xch, 0, (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4), (hipStream_t)stream) != hipSuccess)
-                return tfail(t, DP_ERR_DEVICE, "dp_temporal_predict: cannot reset the exchange area");
-            t->epoch = 0;
-        }
-        a.G = G; a.xch = t->d_xch; a.tstatus = (int*)((char*)t->d_xch + (size_t)t->n_cu * 2 * XCH_GRANULES * sizeof(f4)); a.epoch0 = t->epoch;
-        t->epoch += calls;
+        const int max_teams = t->n_cu / 2 > 0 ? t->n_cu / 2 : 1;
+        a.G = G; a.xch = t->d_xch; a.epochs = (unsigned*)((char*)t->d_xch + t->xch_granule_bytes); a.tstatus = (int*)(a.epochs + max_teams);
         hipLaunchKernelGGL((dp_temporal_kernel<2, 1, true>), dim3(n_seq * G), dim3(NT), 0, (hipStream_t)stream, a);
     } else if (variant == 21) hipLaunchKernelGGL((dp_temporal_kernel<2, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
     else if (variant == 41) hipLaunchKernelGGL((dp_temporal_kernel<4, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);

@@ -68,6 +68,35 @@ def test_native_predictor_matches_nn_transformer_at_full_size(window, variant):
     assert err <= 1e-5, err
 
 
+def test_team_launch_is_replayable_from_a_graph():
+    """The teams' exchange tags live in device memory, not in kernel arguments: a captured dp_temporal_predict launch replayed over new
+    inputs gives what eager launches give (a frozen tag would let a replay take the previous replay's partial sums for its own)."""
+    from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
+
+    torch.manual_seed(4)
+    nat = NativeTemporal(TemporalPredictor().eval(), torch.zeros(24), torch.ones(24), device="cuda:0")
+    S, window = 3, 16
+    g = torch.Generator().manual_seed(21)
+    draw = lambda: (torch.randn(S, 60, 24, generator=g).cuda(), (0.02 * torch.randn(S, 60, 3, generator=g)).cuda(), (1.0 + 0.3 * torch.randn(S, 60, 6, generator=g)).cuda())
+    lat, disp, hts = draw()
+    out = torch.empty(S, window + 1, 24, device="cuda:0")
+    nat.predict(lat, disp, hts, window, out=out)  # (what the library picks for 3 sequences: teams of 16)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        nat.predict(lat, disp, hts, window, out=out)
+    for _ in range(4):
+        a, b, c = draw()
+        lat.copy_(a); disp.copy_(b); hts.copy_(c)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        want = nat.predict(a, b, c, window)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    assert nat._team_status() == 0
+
+
 @pytest.mark.parametrize("occ", [21, 41, 42])  # (42 is not applicable beyond 16 tokens: the library falls back to 41)
 def test_more_than_sixteen_tokens_take_two_tiles(occ):
     """window 100 = 26 autoregressive calls, the last ones over 17..26 target tokens: two 16-token tiles in every product,

@@ -9,8 +9,9 @@ from dragposer_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "_scratch", "lib_tstamps.so")
 from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
 
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-window = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+S = int(_pos[0]) if len(_pos) > 0 else 1
+window = int(_pos[1]) if len(_pos) > 1 else 0
 torch.manual_seed(0)
 dev = torch.device("cuda:0")
 nat = NativeTemporal(TemporalPredictor().eval(), torch.zeros(24), torch.ones(24), device=dev)
@@ -27,7 +28,8 @@ lib.dp_temporal_debug_read_stamps(buf, 4096)
 nat.predict(lat, disp, hts, window, out=out)
 n = lib.dp_temporal_debug_read_stamps(buf, 4096)
 NAMES = {0: "entry", 1: "lin_qkv", 2: "attention", 3: "out_proj", 4: "add_ln", 5: "ffn", 10: "tokens", 11: "in_proj_enc", 12: "enc_norm+mem", 13: "in_proj_dec",
-         14: "final_ln+next_token", 15: "store"}
+         14: "final_ln+next_token", 15: "store", 20: "att: K in registers", 21: "att: turns done", 22: "qkv: wave 0 done", 23: "ffn: tiles done",
+         24: "ffn: reduced + published", 25: "ln: wave 0 done"}
 st = [(int(buf[i]) >> 48, int(buf[i]) & 0xFFFFFFFFFFFF) for i in range(n)]
 tot = {}
 for (i0, t0), (i1, t1) in zip(st[:-1], st[1:]):
@@ -37,3 +39,7 @@ whole = st[-1][1] - st[0][1]
 print(f"S = {S}, window {window}: {n} stamps, {whole} ticks of 10 ns = {whole / 100:.1f} us from entry to the last store (s_memtime is a 100 MHz counter)")
 for k, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"  {NAMES.get(k, k):>20}: {c:4d} x  {t / c / 100:7.2f} us  = {t / 100:7.1f} us  ({100.0 * t / whole:4.1f} %)")
+if "--timeline" in sys.argv:
+    print("timeline (cycles since entry, delta, stamp):")
+    for (i0, t0), (i1, t1) in zip(st[:-1], st[1:]):
+        print(f"  {t1 - st[0][1]:8d} {t1 - t0:7d}  {NAMES.get(i1, i1)}")
