@@ -6,8 +6,8 @@
 // SEQUENCE (or per two, when there are many: below) that runs the whole block -- token assembly from the history buffers, the encoder once, window / step + 1
 // autoregressive decoder calls (the reference passes no target mask, so every call recomputes all target positions),
 // de-normalisation and the step-hold "lerp" -- with every activation in LDS and the weights (5 MB fp32 at the reference's
-// size) streamed from L2.  All linear weights are stored TRANSPOSED ([in][out]) by dp_temporal_create, so that the lanes
-// of a wave, which own consecutive output columns, read consecutive words.
+// size) streamed from L2.  The small linear weights keep torch's [out][in] layout (rows padded to a multiple of four floats): a lane
+// reads a quarter of a row in 16-byte words (lin).
 // Every product runs on v_mfma_f32_16x16x4_f32 with the (at most 16, else tiled) tokens as one tile dimension:
 //   * linear layers: M = token, N = output channel, K = input channel; A from LDS, B one coalesced word per lane and K-step;
 //   * the feed-forward block (48 -> F -> 48, 94 % of the FLOPs and of the weight bytes), per tile of 16 hidden units:
@@ -88,12 +88,36 @@ template <int NS> DEV int row_of(int g, int R, int R2)
     return R == 8 ? ((g >> 3) << 4) + (g & 7) : ((g >> 4) << 3) + (g & 15);
 }
 
-// out[t][n] = b[col0 + n] + sum_k in[t][k] * wT[k][col0 + n] (+ pe[pos(t)][n])   (n < N, k < K <= 4 KS; wT has ldw columns)
-// One 16 x 16 output tile per wave and turn: A[token][k] from LDS, B[k][n] one word per lane and K-step -- all KS loads
-// of a tile in flight together.
+// KS consecutive floats at p (16-byte aligned when KS is a multiple of 4, 8-byte when even): the fewest loads -- the token-wise products of this
+// file are bound by the NUMBER of instructions a lone wave issues (profiles/r05_temporal_phases_team.txt), and a lane's K values are consecutive
+// in memory by the choice of which K-steps a lane serves (below)
+template <int KS> DEV void read_k(float (&v)[KS], const float* p)
+{
+    if constexpr (KS % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < KS / 4; ++i) {
+            const f4 t = *(const f4*)(p + 4 * i);
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+        }
+    } else if constexpr (KS % 2 == 0) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < KS / 2; ++i) {
+            const f2 t = *(const f2*)(p + 2 * i);
+            v[2 * i] = t[0]; v[2 * i + 1] = t[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) v[i] = p[i];
+    }
+}
+
+// out[t][n] = b[n] + sum_k in[t][k] * W[n][k] (+ pe[pos(t)][n])   (n < N, k < K <= 4 KS; W = Linear.weight, rows padded to 4 KS floats)
+// One 16 x 16 output tile per wave and turn.  An MFMA K-step takes four k values, one per lane group q; WHICH four is free as long as both
+// operands agree: lane group q serves k = KS q + ks in step ks, so its KS values of a row are consecutive -- of the activations in LDS and of
+// the weight row in memory: 3 + 3 16-byte loads per tile where 4 ks + q needed 12 + 12 single words, each with its own address arithmetic.
 template <int KS, int NS>
-DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* wT, int ldw, int col0, const float* b, int N, int K,
-             const float* pe = nullptr, int Rin = 0)
+DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* W, const float* b, int N, int K, const float* pe = nullptr, int Rin = 0)
 { // rows per sequence of `out`: rows_per_seq(T); of `in`: Rin (0: the same)
     const int R = rows_per_seq<NS>(T);
     if (Rin == 0) Rin = R;
@@ -109,10 +133,12 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
         const int rin = row_of<NS>(16 * tt + l16, R, Rin);
         float bw[KS], av[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 4 * ks + q;
-            bw[ks] = (k < K && n < N) ? wT[(size_t)k * ldw + col0 + n] : 0.f;
-            av[ks] = (k < K && rv) ? in[rin * ldi + k] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) bw[ks] = av[ks] = 0.f;
+        if (n < N) read_k<KS>(bw, W + (size_t)n * (4 * KS) + KS * q); // (columns k >= K of a weight row are zero: the packer pads)
+        if (rv) read_k<KS>(av, in + rin * ldi + KS * q);
+        if (4 * KS > K) { // (the activation row may hold anything beyond K: keep it out of the products -- 0 * NaN)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) if (KS * q + ks >= K) av[ks] = 0.f;
         }
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -121,7 +147,7 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
             if (ks + 1 < KS) acc1 = mfma(av[ks + 1], bw[ks + 1], acc1);
         }
         if (n < N) {
-            const float bias = b[col0 + n];
+            const float bias = b[n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = 16 * tt + 4 * q + r;
@@ -135,7 +161,7 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
 // the next target token of every sequence: out_proj of its LAST position (row T - 1 of its tile) -> 24 channels; the
 // sequences are the rows of one MFMA tile
 template <int NS>
-DEV void next_token(float* tok, float* preds, const float* x, int T, int it, bool feed, const float* wT, const float* b)
+DEV void next_token(float* tok, float* preds, const float* x, int T, int it, bool feed, const float* W, const float* b)
 { // (x in the layout of rows_per_seq(T) rows per sequence; tok keeps 16 rows per sequence whatever the calls' layouts are)
     const int R = rows_per_seq<NS>(T);
     int lane = threadIdx.x & 63;
@@ -145,11 +171,9 @@ DEV void next_token(float* tok, float* preds, const float* x, int T, int it, boo
         const int n = 16 * wave + l16;
         float bw[D / 4], av[D / 4];
 #pragma unroll
-        for (int ks = 0; ks < D / 4; ++ks) {
-            const int k = 4 * ks + q;
-            bw[ks] = n < LAT ? wT[k * LAT + n] : 0.f;
-            av[ks] = l16 < NS ? x[((NS == 1 ? 0 : R * l16) + T - 1) * D + k] : 0.f;
-        }
+        for (int ks = 0; ks < D / 4; ++ks) bw[ks] = av[ks] = 0.f;
+        if (n < LAT) read_k<D / 4>(bw, W + n * D + (D / 4) * q); // (lane group q serves k = 12 q + ks: lin)
+        if (l16 < NS) read_k<D / 4>(av, x + ((NS == 1 ? 0 : R * l16) + T - 1) * D + (D / 4) * q);
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
         for (int ks = 0; ks < D / 4; ks += 2) {
@@ -223,10 +247,10 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
     __syncthreads();
 }
 
-// q | k | v = in_proj(xq | xkv | xkv) in ONE phase: the nine 16-column tiles of the packed in_proj weight [48][144] (x token
-// tiles) are dealt to the waves; columns 0..47 take the query tokens, the rest the key / value tokens.
+// q | k | v = in_proj(xq | xkv | xkv) in ONE phase: the nine 16-row tiles of the packed in_proj weight [144][48] (x token
+// tiles) are dealt to the waves; output channels 0..47 take the query tokens, the rest the key / value tokens.
 template <int NS>
-DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* wT, const float* b)
+DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* W, const float* b)
 { // (q rows in the layout of rows_per_seq(Tq) rows per sequence, k / v rows in that of rows_per_seq(Tk))
     const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     int lane = threadIdx.x & 63;
@@ -242,11 +266,9 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
         const bool rv = row_valid<NS>(16 * tt + l16, Tj, Rj);
         float bw[D / 4], av[D / 4];
 #pragma unroll
-        for (int ks = 0; ks < D / 4; ++ks) {
-            const int k = 4 * ks + qd;
-            bw[ks] = wT[k * 3 * D + n];
-            av[ks] = rv ? in[(16 * tt + l16) * D + k] : 0.f;
-        }
+        for (int ks = 0; ks < D / 4; ++ks) av[ks] = 0.f;
+        read_k<D / 4>(bw, W + n * D + (D / 4) * qd);
+        if (rv) read_k<D / 4>(av, in + (16 * tt + l16) * D + (D / 4) * qd);
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
         for (int ks = 0; ks < D / 4; ks += 2) {
@@ -346,7 +368,7 @@ DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const 
     STAMP(1);
     attention<NS>(ao, q, k, v, sc, Tq, Tk);
     STAMP(2);
-    lin<D / 4, NS>(o, D, ao, D, Tq, w + out_wT, D, 0, w + out_b, D, D);
+    lin<D / 4, NS>(o, D, ao, D, Tq, w + out_wT, w + out_b, D, D);
     STAMP(3);
 }
 
@@ -404,6 +426,27 @@ struct Team { // (uniform per workgroup)
     int g, G;      // this workgroup's rank in its team, the team's size (2, 4, 8 or 16)
     int* dead;     // (LDS) an exchange of this workgroup has timed out: no further waiting
 };
+
+// a thread's three outputs: re-read the GG members' granules until all carry the awaited tag, then add them up in member order
+template <int GG> DEV void gather(float (&sum)[3], const f4* src, Team* tm)
+{
+    f4 v[16];
+    const bool dead = *tm->dead != 0;
+    for (int tries = 0;;) {
+        load_granules<GG>(v, src);
+        bool all = true;
+#pragma unroll
+        for (int gg = 0; gg < GG; ++gg) all = all && __float_as_uint(v[gg][3]) == tm->tag;
+        if (all || dead) break;
+        if (++tries >= XCH_POLL_LIMIT) { *tm->status = 1; *tm->dead = 1; break; } // (gives up: on with what is there, no further waiting)
+        __builtin_amdgcn_s_sleep(2);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int gg = 0; gg < GG; ++gg) sum[j] += v[gg][j];
+    }
+}
 
 // one tile of 16 hidden units: H^T = W1 X^T (12 MFMAs), bias + ReLU, OUT += H W2^T (12 MFMAs; the first product's
 // accumulator is the second's A operand)
@@ -557,28 +600,16 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
         const int i = threadIdx.x, tt = i >> 8, il = i & 255, tl = il >> 4, c0 = 3 * (il & 15);
         if (tt < ntt && row_valid<NS>(16 * tt + tl, T, R)) {
             const f4* src = xslot + (size_t)i * XCH_GMAX;
-            f4 v[16];
-            const int G = tm->G;
-            const bool dead = *tm->dead != 0;
-            for (int tries = 0;;) {
-                if (G == 16) load_granules<16>(v, src);
-                else if (G == 8) load_granules<8>(v, src);
-                else if (G == 4) load_granules<4>(v, src);
-                else load_granules<2>(v, src);
-                bool all = true;
-#pragma unroll
-                for (int gg = 0; gg < 16; ++gg) if (gg < G) all = all && __float_as_uint(v[gg][3]) == tm->tag;
-                if (all || dead) break;
-                if (++tries >= XCH_POLL_LIMIT) { *tm->status = 1; *tm->dead = 1; break; } // (gives up: on with what is there, no further waiting)
-                __builtin_amdgcn_s_sleep(2);
+            float sum[3] = {w[l2b + c0], w[l2b + c0 + 1], w[l2b + c0 + 2]};
+            // (one copy of the loop per team size: sixteen "member < G" predicates kept across the layer loops cost the kernel 200 scalar spills)
+            switch (tm->G) {
+            case 16: gather<16>(sum, src, tm); break;
+            case 8: gather<8>(sum, src, tm); break;
+            case 4: gather<4>(sum, src, tm); break;
+            default: gather<2>(sum, src, tm); break;
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float sum = w[l2b + c0 + j];
-#pragma unroll
-                for (int gg = 0; gg < 16; ++gg) if (gg < G) sum += v[gg][j];
-                o[(16 * tt + tl) * D + c0 + j] = sum;
-            }
+            for (int j = 0; j < 3; ++j) o[(16 * tt + tl) * D + c0 + j] = sum[j];
         }
         __syncthreads();
         tm->tag += 1u;
@@ -593,13 +624,13 @@ template <int OCC, int NS, bool TEAM = false>
 __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
 {
     static_assert(!TEAM || NS == 1, "a team runs one sequence");
-    __shared__ float mem[MAXT * D], x[MAXT * D], o[MAXT * D];
+    __shared__ __attribute__((aligned(16))) float mem[MAXT * D], x[MAXT * D], o[MAXT * D]; // (rows are read in 16-byte words: lin)
     // q, k, v and the attention output; dead while the feed-forward block runs, whose cross-wave reduction buffer is the
     // same 24 KB (70 KB of LDS in all: two workgroups per CU)
     __shared__ __attribute__((aligned(16))) float qkva[4 * MAXT * D];
     static_assert(4 * MAXT * D >= NWV * 3 * 64 * 4, "the reduction buffer fits the attention buffers");
     float *q = qkva, *kb = qkva + MAXT * D, *vb = qkva + 2 * MAXT * D, *ao = qkva + 3 * MAXT * D, *red = qkva;
-    __shared__ float sc[NHD * MAXT * MAXT], tok[MAXT * LAT], enc_in[MAXT * MAX_IN], preds[NS * (MAXT + 1) * LAT];
+    __shared__ __attribute__((aligned(16))) float sc[NHD * MAXT * MAXT], tok[MAXT * LAT], enc_in[MAXT * MAX_IN], preds[NS * (MAXT + 1) * LAT];
     const int s0 = TEAM ? (int)blockIdx.x / a.G : (int)blockIdx.x * NS, tid = threadIdx.x;
     if (s0 >= a.n_seq) return;
     __shared__ int team_dead;
@@ -638,7 +669,7 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     STAMP(10);
 
     // ---- encoder, once (the memory is the same for every autoregressive call)
-    lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, D, 0, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
+    lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
     STAMP(11);
     for (int l = 0; l < a.n_enc; ++l) {
         const TLayer L = tab[l];
@@ -664,7 +695,7 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         const int T = it + 1;
         // (the activations of a call over at most 8 tokens take 8 rows per sequence: two sequences share a tile -- rows_per_seq; the token buffer
         //  keeps 16, the memory the layout of its own token count)
-        lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, D, 0, w + a.ipd_b, D, LAT, w + a.pe, 16);
+        lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, w + a.ipd_b, D, LAT, w + a.pe, 16);
         STAMP(13);
         for (int l = 0; l < a.n_dec; ++l) {
             const TLayer L = tab[a.n_enc + l];
@@ -743,12 +774,14 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
         buf.insert(buf.end(), p, p + n);
         return off;
     };
-    auto putT = [&](const float* p, int rows_out, int cols_in) { // Linear.weight [out][in] -> [in][out]
+    auto putT = [&](const float* p, int rows_out, int cols_in, int ldk = 0) { // Linear.weight [out][in] as it is, rows padded with zeros to a multiple of 4 (or to ldk)
+        while (buf.size() % 4) buf.push_back(0.f);               // floats and 16-byte aligned (lin: a lane reads KS consecutive floats of a row)
         const int off = (int)buf.size();
-        buf.resize(buf.size() + (size_t)rows_out * cols_in, 0.f);
+        if (ldk == 0) ldk = (cols_in + 3) / 4 * 4;
+        buf.resize(buf.size() + (size_t)rows_out * ldk, 0.f);
         if (!p) { null_seen = true; return off; }
         for (int r = 0; r < rows_out; ++r)
-            for (int c = 0; c < cols_in; ++c) buf[off + (size_t)c * rows_out + r] = p[(size_t)r * cols_in + c];
+            for (int c = 0; c < cols_in; ++c) buf[off + (size_t)r * ldk + c] = p[(size_t)r * cols_in + c];
         return off;
     };
     // feed-forward image, per tile of 16 hidden units and lane (token / channel l16 = lane & 15, q = lane >> 4), 7 float4:
@@ -784,7 +817,7 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     TArgs a{};
     a.n_enc = m->n_encoder_layers; a.n_dec = m->n_decoder_layers; a.ff = F; a.n_in = n_in; a.nh = m->n_heights;
     a.max_len = m->max_len; a.step = m->sample_step;
-    a.ipe_wT = putT(m->in_proj_encoder_w, D, n_in); a.ipe_b = put(m->in_proj_encoder_b, D);
+    a.ipe_wT = putT(m->in_proj_encoder_w, D, n_in, MAX_IN); a.ipe_b = put(m->in_proj_encoder_b, D); // (the kernel's K-steps cover MAX_IN inputs)
     a.ipd_wT = putT(m->in_proj_decoder_w, D, LAT); a.ipd_b = put(m->in_proj_decoder_b, D);
     a.op_wT = putT(m->out_proj_w, LAT, D); a.op_b = put(m->out_proj_b, LAT);
     a.pe = put(m->pos_encoding, (size_t)m->max_len * D);

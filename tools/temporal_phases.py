@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where the cycles of ONE dp_temporal_predict launch go (the -DDPT_STAMPS build, tools/temporal_phases.sh).
-Usage: tools/temporal_phases.py [S=1] [window=0]   (prints per phase kind: count, total cycles of the 100 MHz s_memtime clock -> us)"""
+Usage: tools/temporal_phases.py [S=1] [window=0]   (prints per phase kind: count, shader cycles per call, total)"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,9 +36,11 @@ for (i0, t0), (i1, t1) in zip(st[:-1], st[1:]):
     c, t = tot.get(i1, (0, 0))
     tot[i1] = (c + 1, t + (t1 - t0))
 whole = st[-1][1] - st[0][1]
-print(f"S = {S}, window {window}: {n} stamps, {whole} ticks of 10 ns = {whole / 100:.1f} us from entry to the last store (s_memtime is a 100 MHz counter)")
+GHZ = 2.4  # (s_memtime counts shader cycles; the steady clock under this load is 2.38-2.40 GHz: profiles/r05_clock_ramp.txt)
+print(f"S = {S}, window {window}: {n} stamps, {whole} shader cycles = {whole / GHZ / 1e3:.1f} us at {GHZ} GHz from entry to the last store "
+      f"(a stamp costs about 200 cycles: the unstamped kernel is that much faster per stamp)")
 for k, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {NAMES.get(k, k):>20}: {c:4d} x  {t / c / 100:7.2f} us  = {t / 100:7.1f} us  ({100.0 * t / whole:4.1f} %)")
+    print(f"  {NAMES.get(k, k):>26}: {c:4d} x  {t / c:8.0f} cycles = {t / GHZ / 1e3:6.1f} us  ({100.0 * t / whole:4.1f} %)")
 if "--timeline" in sys.argv:
     print("timeline (cycles since entry, delta, stamp):")
     for (i0, t0), (i1, t1) in zip(st[:-1], st[1:]):
