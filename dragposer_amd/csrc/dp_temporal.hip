@@ -28,6 +28,7 @@ namespace {
 constexpr int D = DP_TEMPORAL_D_MODEL, NHD = DP_TEMPORAL_HEADS, HD = D / NHD, LAT = 24;
 constexpr int MAXT = DP_TEMPORAL_MAX_TOKENS, MAXL = DP_TEMPORAL_MAX_LAYERS;
 constexpr int NT = 512, NWV = NT / 64;              // threads / waves per workgroup (two waves per SIMD)
+constexpr int LN_MAX = (MAXL * 4 + MAXL * 6 + 4) * D;  // floats of the LayerNorm block at the largest architecture
 constexpr int MAX_IN = 36;                          // 24 + 3 + 8 heights, padded to a multiple of 4 (K-steps)
 constexpr int FFN_TILE_FLOATS = 7 * 64 * 4;         // packed feed-forward weights of one 16-unit tile: 7 float4 per lane
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -42,6 +43,7 @@ struct TArgs {
                           // layer loop would be copied into registers: 288 SGPRs)
     int n_enc, n_dec, ff, n_in, nh, max_len, step;
     int ipe_wT, ipe_b, ipd_wT, ipd_b, op_wT, op_b, pe, encn_w, encn_b, decn_w, decn_b, mean, stdv;
+    int ln0, ln_len; // all LayerNorm rows (the layers' and the two final ones) are one block: the TEAM kernel keeps it in LDS
     // per call
     const float *latent_buf, *disp_buf, *heights_buf;
     float* target;
@@ -257,30 +259,45 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
     asm volatile("" : "+v"(lane)); // (as in lin)
     const int wave = threadIdx.x >> 6, l16 = lane & 15, qd = lane >> 4;
     const int ttq = n_ttiles<NS>(Tq, Rq), ttk = n_ttiles<NS>(Tk, Rk), jobs = 3 * ttq + 6 * ttk;
+    // a wave takes its jobs two at a time -- job and job + 8 (with nine jobs only wave 0 has a second one): both jobs' operands are requested
+    // before the first product (a weight row comes from cold memory: the second round trip is what the other seven waves would wait for)
 #pragma unroll 1
-    for (int job = wave; job < jobs; job += NWV) {
-        const bool isq = job < 3 * ttq;
-        const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : j2 / 6;
-        const float* in = isq ? xq : xkv;
-        const int Tj = isq ? Tq : Tk, Rj = isq ? Rq : Rk, n = 16 * nt + l16;
-        const bool rv = row_valid<NS>(16 * tt + l16, Tj, Rj);
-        float bw[D / 4], av[D / 4];
+    for (int job0 = wave; job0 < jobs; job0 += 2 * NWV) {
+        float bw[2][D / 4], av[2][D / 4];
+        int nn[2], tts[2];
+        bool isqs[2];
+        const bool two = job0 + NWV < jobs; // (uniform)
 #pragma unroll
-        for (int ks = 0; ks < D / 4; ++ks) av[ks] = 0.f;
-        read_k<D / 4>(bw, W + n * D + (D / 4) * qd);
-        if (rv) read_k<D / 4>(av, in + (16 * tt + l16) * D + (D / 4) * qd);
-        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int u = 0; u < 2; ++u) {
+            const int job = job0 + u * NWV;
+            const bool isq = job < 3 * ttq;
+            const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : j2 / 6;
+            const float* in = isq ? xq : xkv;
+            const int Tj = isq ? Tq : Tk, Rj = isq ? Rq : Rk, n = 16 * nt + l16;
+            nn[u] = n; tts[u] = tt; isqs[u] = isq;
+            const bool on = u == 0 || two;
 #pragma unroll
-        for (int ks = 0; ks < D / 4; ks += 2) {
-            acc0 = mfma(av[ks], bw[ks], acc0);
-            acc1 = mfma(av[ks + 1], bw[ks + 1], acc1);
+            for (int ks = 0; ks < D / 4; ++ks) bw[u][ks] = av[u][ks] = 0.f;
+            if (on) read_k<D / 4>(bw[u], W + n * D + (D / 4) * qd); // (lane group qd serves k = 12 qd + ks: lin)
+            if (on && row_valid<NS>(16 * tt + l16, Tj, Rj)) read_k<D / 4>(av[u], in + (16 * tt + l16) * D + (D / 4) * qd);
         }
-        const float bias = b[n];
-        float* out = qkv + (n / D) * (MAXT * D) + (n % D); // q, k, v are consecutive [MAXT][D] arrays
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int g = 16 * tt + 4 * qd + r;
-            if (row_valid<NS>(g, Tj, Rj)) out[g * D] = acc0[r] + acc1[r] + bias;
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int ks = 0; ks < D / 4; ks += 2) {
+                acc0 = mfma(av[u][ks], bw[u][ks], acc0);
+                acc1 = mfma(av[u][ks + 1], bw[u][ks + 1], acc1);
+            }
+            const int n = nn[u], Tj = isqs[u] ? Tq : Tk, Rj = isqs[u] ? Rq : Rk;
+            const float bias = b[n];
+            float* out = qkv + (n / D) * (MAXT * D) + (n % D); // q, k, v are consecutive [MAXT][D] arrays
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = 16 * tts[u] + 4 * qd + r;
+                if (row_valid<NS>(g, Tj, Rj)) out[g * D] = acc0[r] + acc1[r] + bias;
+            }
         }
     }
     STAMP(22);
@@ -309,30 +326,29 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
         const bool live0 = j < Tk, live1 = j + 16 < Tk;
         float k0[HD], k1[HD];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            k0[c] = live0 ? k[j * D + h * HD + c] : 0.f;
-            k1[c] = live1 ? k[(j + 16) * D + h * HD + c] : 0.f;
-        }
+        for (int c = 0; c < HD; ++c) k0[c] = k1[c] = 0.f;
+        if (live0) read_k<HD>(k0, k + j * D + h * HD); // (a head's 12 channels: three 16-byte words)
+        if (live1) read_k<HD>(k1, k + (j + 16) * D + h * HD);
         STAMP(20);
         float* sch = sc + (NS == 1 ? h * MAXT * MAXT : wave * 16 * MAXT);
         const int iq = lane / HD, cq = lane - iq * HD; // second half of a turn: lane (query iq of the turn, channel cq), lanes 0 .. 47
 #pragma unroll 1
         for (int i0 = 4 * part; i0 < Tq; i0 += 4 * SHARE) {
             const int i = min(i0 + r, Tq - 1); // (a row beyond the last query recomputes it)
-            float s0 = 0.f, s1 = 0.f;
+            float s0 = 0.f, s1 = 0.f, qv[HD];
+            read_k<HD>(qv, q + i * D + h * HD);
 #pragma unroll
             for (int c = 0; c < HD; ++c) {
-                const float qc = q[i * D + h * HD + c];
-                s0 = fmaf(qc, k0[c], s0);
-                s1 = fmaf(qc, k1[c], s1);
+                s0 = fmaf(qv[c], k0[c], s0);
+                s1 = fmaf(qv[c], k1[c], s1);
             }
             s0 = live0 ? s0 * scale : -3.0e38f;
             s1 = live1 ? s1 * scale : -3.0e38f;
             const float m = row_max(fmaxf(s0, s1));
             const float e0 = live0 ? expf(s0 - m) : 0.f, e1 = live1 ? expf(s1 - m) : 0.f;
             const float inv = 1.f / row_sum(e0 + e1);
-            if (live0) sch[i * MAXT + j] = e0 * inv;
-            if (live1) sch[i * MAXT + j + 16] = e1 * inv;
+            sch[i * MAXT + j] = e0 * inv; // (a key beyond the last: probability 0, so that the rows below can be read eight at a time)
+            sch[i * MAXT + j + 16] = e1 * inv;
             // (LDS operations of a wave execute in order: the probabilities written above are visible below)
             const int io = i0 + iq;
             if (iq < 4 && io < Tq) {
@@ -342,14 +358,11 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
 #pragma unroll 1
                 for (int j0 = 0; j0 < Tk; j0 += 8) {
                     float pj[8], vj[8];
+                    read_k<8>(pj, p + j0);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool in = j0 + u < Tk;
-                        pj[u] = in ? p[j0 + u] : 0.f;
-                        vj[u] = in ? vc[(j0 + u) * D] : 0.f;
-                    }
+                    for (int u = 0; u < 8; ++u) vj[u] = vc[min(j0 + u, Tk - 1) * D]; // (beyond the last key: its probability is 0, the value any finite one)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc = fmaf(pj[u], vj[u], acc); // (a key beyond the last adds 0 * 0: nothing)
+                    for (int u = 0; u < 8; ++u) acc = fmaf(pj[u], vj[u], acc);
                 }
                 ao[io * D + h * HD + cq] = acc;
             }
@@ -644,6 +657,12 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     const float* w = a.w;
     STAMP(0);
     const TLayer* tab = (const TLayer*)(w + a.enc_tab); // (encoder layers, then decoder layers: one table)
+    // TEAM: the LayerNorm rows in LDS (17 LayerNorms of one token each stand in the decoder's latency chain: their two rows came from cold memory)
+    __shared__ float lnrows[TEAM ? LN_MAX : 1];
+    if constexpr (TEAM) {
+        for (int i = tid; i < a.ln_len; i += NT) lnrows[i] = w[a.ln0 + i]; // (visible after the token assembly's barrier)
+    }
+    const float* wl = TEAM ? lnrows - a.ln0 : w; // what the LayerNorm row offsets are relative to
     const int H = a.H, step = a.step, n_past = (H + step - 1) / step, Te = n_past - 1, n_steps = a.window / step + 1;
 
     // ---- tokens (drag_pose.py:249-266): latent normalised | displacement accumulated over `step` frames | heights.
@@ -676,16 +695,16 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         f4 pre[7];
         if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
         mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
-        add_ln<NS>(x, o, Te, w + L.n1w, w + L.n1b);
+        add_ln<NS>(x, o, Te, wl + L.n1w, wl + L.n1b);
         STAMP(4);
         if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, &team, &pre);
         else if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform; a history of at most 8 tokens)
         else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
         STAMP(5);
-        add_ln<NS>(x, o, Te, w + L.n2w, w + L.n2b);
+        add_ln<NS>(x, o, Te, wl + L.n2w, wl + L.n2b);
         STAMP(4);
     }
-    add_ln<NS>(x, nullptr, Te, w + a.encn_w, w + a.encn_b);
+    add_ln<NS>(x, nullptr, Te, wl + a.encn_w, wl + a.encn_b);
     for (int idx = tid; idx < MAXT * D; idx += NT) mem[idx] = x[idx];
     __syncthreads();
     STAMP(12);
@@ -702,19 +721,19 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
             f4 pre[7];
             if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
             mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
-            add_ln<NS>(x, o, T, w + L.n1w, w + L.n1b);
+            add_ln<NS>(x, o, T, wl + L.n1w, wl + L.n1b);
             STAMP(4);
             mha<NS>(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
-            add_ln<NS>(x, o, T, w + L.n2w, w + L.n2b);
+            add_ln<NS>(x, o, T, wl + L.n2w, wl + L.n2b);
             STAMP(4);
             if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, &team, &pre);
             else if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform)
             else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
             STAMP(5);
-            add_ln<NS>(x, o, T, w + L.n3w, w + L.n3b);
+            add_ln<NS>(x, o, T, wl + L.n3w, wl + L.n3b);
             STAMP(4);
         }
-        add_ln<NS>(x, nullptr, T, w + a.decn_w, w + a.decn_b);
+        add_ln<NS>(x, nullptr, T, wl + a.decn_w, wl + a.decn_b);
         STAMP(4);
         next_token<NS>(tok, preds, x, T, it, it + 1 < n_steps, w + a.op_wT, w + a.op_b);
         STAMP(14);
@@ -814,6 +833,13 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
             }
         return off;
     };
+    std::vector<float> lnbuf; // the LayerNorm rows, appended to buf as one block below (offsets are relative until then)
+    auto put_ln = [&](const float* p) {
+        const int off = (int)lnbuf.size();
+        if (!p) { null_seen = true; lnbuf.resize(lnbuf.size() + D, 0.f); return off; }
+        lnbuf.insert(lnbuf.end(), p, p + D);
+        return off;
+    };
     TArgs a{};
     a.n_enc = m->n_encoder_layers; a.n_dec = m->n_decoder_layers; a.ff = F; a.n_in = n_in; a.nh = m->n_heights;
     a.max_len = m->max_len; a.step = m->sample_step;
@@ -821,8 +847,8 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     a.ipd_wT = putT(m->in_proj_decoder_w, D, LAT); a.ipd_b = put(m->in_proj_decoder_b, D);
     a.op_wT = putT(m->out_proj_w, LAT, D); a.op_b = put(m->out_proj_b, LAT);
     a.pe = put(m->pos_encoding, (size_t)m->max_len * D);
-    a.encn_w = put(m->enc_norm_w, D); a.encn_b = put(m->enc_norm_b, D);
-    a.decn_w = put(m->dec_norm_w, D); a.decn_b = put(m->dec_norm_b, D);
+    a.encn_w = put_ln(m->enc_norm_w); a.encn_b = put_ln(m->enc_norm_b);
+    a.decn_w = put_ln(m->dec_norm_w); a.decn_b = put_ln(m->dec_norm_b);
     a.mean = put(m->means_latent, LAT); a.stdv = put(m->stds_latent, LAT);
     if (!m->enc || !m->dec) return tfail(nullptr, DP_ERR_INVALID, "dp_temporal_create: NULL layer array");
     auto layer = [&](const dp_temporal_layer& L, bool dec) {
@@ -835,14 +861,19 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
         }
         o.ffn_pack = pack_ffn(L.lin1_w, L.lin1_b, L.lin2_w);
         o.lin2_b = put(L.lin2_b, D);
-        o.n1w = put(L.norm1_w, D); o.n1b = put(L.norm1_b, D);
-        o.n2w = put(L.norm2_w, D); o.n2b = put(L.norm2_b, D);
-        if (dec) { o.n3w = put(L.norm3_w, D); o.n3b = put(L.norm3_b, D); }
+        o.n1w = put_ln(L.norm1_w); o.n1b = put_ln(L.norm1_b);
+        o.n2w = put_ln(L.norm2_w); o.n2b = put_ln(L.norm2_b);
+        if (dec) { o.n3w = put_ln(L.norm3_w); o.n3b = put_ln(L.norm3_b); }
         return o;
     };
     std::vector<TLayer> tabs;
     for (int l = 0; l < a.n_enc; ++l) tabs.push_back(layer(m->enc[l], false));
     for (int l = 0; l < a.n_dec; ++l) tabs.push_back(layer(m->dec[l], true));
+    while (buf.size() % 4) buf.push_back(0.f);
+    a.ln0 = (int)buf.size(); a.ln_len = (int)lnbuf.size();
+    buf.insert(buf.end(), lnbuf.begin(), lnbuf.end());
+    for (TLayer& t : tabs) { t.n1w += a.ln0; t.n1b += a.ln0; t.n2w += a.ln0; t.n2b += a.ln0; t.n3w += a.ln0; t.n3b += a.ln0; } // (n3*: decoder layers only; unused otherwise)
+    a.encn_w += a.ln0; a.encn_b += a.ln0; a.decn_w += a.ln0; a.decn_b += a.ln0;
     static_assert(sizeof(TLayer) % sizeof(float) == 0, "layer tables live in the float buffer");
     a.enc_tab = (int)buf.size();
     a.dec_tab = a.enc_tab + a.n_enc * (int)(sizeof(TLayer) / sizeof(float));

@@ -75,7 +75,8 @@ def test_temporal_kernel_variants_fit_their_occupancy(tmp_path):
     assert len(kernels) == 4, list(notes)
     for name, n in kernels.items():
         assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
-        assert n["lds"] <= 80 * 1024, (name, n)      # two workgroups per CU
+        team = "ILi2ELi1ELb1EE" in name                  # (a team's workgroups have a CU each: n_seq * G <= CUs)
+        assert n["lds"] <= (160 if team else 80) * 1024, (name, n)  # the others: two workgroups per CU
     assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, False, True, True]  # the 2-waves-per-SIMD variants use the full file
 
 
