@@ -323,7 +323,10 @@ const char* dp_temporal_last_error(const dp_temporal* t); /* NULL: last failure 
 /* The temporal target block of one frame step (drag_pose.py:248-292), for S sequences: tokens from the history buffers of
  * `state` (latent normalised, displacement accumulated over sample_step frames, heights), window / sample_step + 1
  * autoregressive calls of the Transformer, de-normalisation and the reference's step-hold "lerp".
- * target_buf (DEVICE) [S][window + 1][24]: row current_index of it is the frame's z_tgt.  Asynchronous on the stream. */
+ * target_buf (DEVICE) [S][window + 1][24]: row current_index of it is the frame's z_tgt.  Asynchronous on the stream.
+ * One launch of a handle at a time (launches on one stream are; two streams sharing a handle must order themselves): up to half as many
+ * sequences as the device has CUs, the workgroups that share a sequence exchange partial sums through memory the handle owns.  Such a launch
+ * may be captured into a graph and replayed (the exchange keeps its counters on the device). */
 int dp_temporal_predict(dp_temporal* t, int n_sequences, const dp_seq_state* state, int window, float* target_buf, void* hip_stream);
 
 /* Device-buffer helpers for callers that have no HIP binding of their own (the native Unity drop-in,

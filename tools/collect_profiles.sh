@@ -41,6 +41,8 @@ echo "rehearsal done"
 python3 tools/time_temporal.py 2>&1 | grep "^window" > $O/temporal_predictor_times.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tstats --output-format csv -- python3 tools/time_temporal.py --native-only > $O/tstats.log 2>&1
 grep "dp_temporal_kernel\|\"Name\"" $(find $O/tstats -name "*kernel_stats.csv" | head -1) > $O/temporal_kernel_stats.csv
+python3 tools/team_latency.py 1 2 4 8 16 32 64 128 2>&1 | grep "^window" > $O/team_latency.txt
+if [ -f _scratch/lib_tstamps.so ]; then python3 tools/temporal_phases.py 1 0 --timeline 2>&1 | grep -v "amdgpu.ids\|Warning\|self.encoder" > $O/temporal_phases_team.txt; fi  # (tools/temporal_phases.sh on the build host first)
 echo "temporal done"
 # 8. the 16-frames-per-wave kernel: BASELINE config 5 through bench.py (the JSON line), kernel trace, batch sweep of both kernels, PMC passes
 python3 bench.py --config s4 --frames 16384 --steps 20 --warmup 3 --no-cpu-baseline --traffic none > $O/bench_s4_16384.json 2> /dev/null
