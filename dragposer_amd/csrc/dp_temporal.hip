@@ -656,7 +656,18 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     }
     const float* w = a.w;
     STAMP(0);
-    const TLayer* tab = (const TLayer*)(w + a.enc_tab); // (encoder layers, then decoder layers: one table)
+    // the layer tables (encoder layers, then decoder layers: one table) in LDS: a layer's sixteen offsets read from memory at the head of the layer
+    // were scalar loads from a cold line -- 3 k cycles in front of every layer of the one-sequence launch (profiles/r05_temporal_phases_team.txt)
+    constexpr int TLW = (int)(sizeof(TLayer) / sizeof(int));
+    __shared__ int ltab[2 * MAXL * TLW];
+    for (int i = tid; i < (a.n_enc + a.n_dec) * TLW; i += NT) ltab[i] = ((const int*)(w + a.enc_tab))[i]; // (visible after the token assembly's barrier)
+    auto layer_of = [&](int li) {
+        TLayer L;
+        int* Lp = (int*)&L;
+#pragma unroll
+        for (int k = 0; k < TLW; ++k) Lp[k] = __builtin_amdgcn_readfirstlane(ltab[li * TLW + k]); // (uniform: back into scalar registers)
+        return L;
+    };
     // TEAM: the LayerNorm rows in LDS (17 LayerNorms of one token each stand in the decoder's latency chain: their two rows came from cold memory)
     __shared__ float lnrows[TEAM ? LN_MAX : 1];
     if constexpr (TEAM) {
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
     STAMP(11);
     for (int l = 0; l < a.n_enc; ++l) {
-        const TLayer L = tab[l];
+        const TLayer L = layer_of(l);
         f4 pre[7];
         if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
         mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         lin<LAT / 4, NS>(x, D, tok, LAT, T, w + a.ipd_wT, w + a.ipd_b, D, LAT, w + a.pe, 16);
         STAMP(13);
         for (int l = 0; l < a.n_dec; ++l) {
-            const TLayer L = tab[a.n_enc + l];
+            const TLayer L = layer_of(a.n_enc + l);
             f4 pre[7];
             if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
             mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
