@@ -54,15 +54,18 @@ class LaunchPlan:
     """A dp_optimize call with its arguments already checked and marshalled (LatentOptimizer.plan).  Holds the input and result
     tensors alive; `plan()` launches on torch's current stream of the optimiser's device and returns the result tensors."""
 
-    __slots__ = ("_opt", "_b", "_p", "_r", "results", "_inputs", "_fn", "_ctx", "_dev")
+    __slots__ = ("_opt", "_b", "_p", "_r", "results", "_inputs", "_fn", "_dev")
 
     def __init__(self, opt, batch, params, res, tensors, inputs):
         self._opt, self.results, self._inputs = opt, tensors, inputs
         self._b, self._p, self._r = C.byref(batch), C.byref(params), C.byref(res)  # (byref objects keep their structs alive)
-        self._fn, self._ctx, self._dev = opt.lib.dp_optimize, opt.ctx, opt.device
+        self._fn, self._dev = opt.lib.dp_optimize, opt.device
 
     def __call__(self):
-        rc = self._fn(self._ctx, self._b, self._p, self._r, torch.cuda.current_stream(self._dev).cuda_stream)
+        ctx = self._opt.ctx  # (read per call: after LatentOptimizer.close() it is NULL and the library refuses, instead of a freed context being used)
+        if not ctx.value:
+            raise _lib.DragPoserError(_lib.DP_ERR_INVALID, "LaunchPlan: the optimiser it was made by has been closed")
+        rc = self._fn(ctx, self._b, self._p, self._r, torch.cuda.current_stream(self._dev).cuda_stream)
         if rc != _lib.DP_OK:
             self._opt._fail(rc)
         return self.results

@@ -230,6 +230,17 @@ def test_launch_plan_repeats_the_call_over_the_same_buffers(opt, golden_dir):
     assert not torch.equal(first, out["z"])
     with pytest.raises(ValueError):
         opt.plan(**{**b, "z0": b["z0"][:, :23]}, n_iter=20)
+    # a plan outliving its optimiser is refused, not run on a freed context
+    from dragposer_amd._lib import DragPoserError
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    o2 = LatentOptimizer(device=opt.device)
+    p2 = o2.plan(**b, n_iter=2)
+    p2()
+    torch.cuda.synchronize()
+    o2.close()
+    with pytest.raises(DragPoserError):
+        p2()
 
 
 @pytest.mark.parametrize("kernel", ["auto", "w16"])
