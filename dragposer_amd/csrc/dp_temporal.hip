@@ -958,6 +958,19 @@ extern "C" int dp_temporal_debug_force_variant(dp_temporal* t, int variant)
     return DP_OK;
 }
 
+// The team size the library picks for n_seq sequences on a device of n_cu CUs (1: no teams).  Host arithmetic only (a CPU test holds it): the
+// largest power of two up to 16 with every workgroup on a CU of its own (team members wait for each other: all of them must be resident, and the
+// TEAM kernel's 86 KB of LDS allow one workgroup per CU) and at least one feed-forward tile per wave; 16 pays with a quarter of the device at most
+// (profiles/r05_team_latency.txt), 8 beyond.
+extern "C" int dp_temporal_debug_team_size(int n_cu, int n_seq, int dim_feedforward)
+{
+    if (n_cu <= 0 || n_seq <= 0 || dim_feedforward <= 0) return 1;
+    int G = 1;
+    while (G < 16 && n_seq * (2 * G) <= n_cu && (dim_feedforward + 15) / 16 >= 2 * G * NWV) G *= 2;
+    if (G == 16 && n_seq * 64 > n_cu) G = 8;
+    return G;
+}
+
 // private test hook: the teams' status word (0: every exchange completed; 1: a workgroup waited XCH_POLL_LIMIT reads for its team -- the launch's
 // predictions are garbage); synchronises the device
 extern "C" int dp_temporal_debug_team_status(dp_temporal* t)
@@ -992,9 +1005,11 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? 42 : 41);
     // few sequences: a TEAM of G workgroups per sequence (the largest power of two up to 16 with every workgroup on a CU of its own -- they wait for
     // each other, so all of them must be resident -- and at least one feed-forward tile per wave)
-    int G = 1;
-    while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + 15) / 16 >= 2 * G * NWV) G *= 2;
-    if (G == 16 && n_seq * 64 > t->n_cu && t->forced_variant < 100) G = 8; // (16 pays with a quarter of the device at most: profiles/r05_team_latency.txt)
+    int G = dp_temporal_debug_team_size(t->n_cu, n_seq, m.ff);
+    if (t->forced_variant >= 100) { // (a forced size: the largest the launch fits, whatever pays)
+        G = 1;
+        while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + 15) / 16 >= 2 * G * NWV) G *= 2;
+    }
     if (t->forced_variant >= 100) { const int want = t->forced_variant - 100; G = G >= want ? want : 1; }
     if (G >= 2 && (t->forced_variant == 0 || t->forced_variant >= 100)) variant = 100 + G;
     if (t->forced_variant == 21 || t->forced_variant == 41 || (t->forced_variant == 42 && pair_ok)) variant = t->forced_variant;

@@ -172,6 +172,19 @@ def test_temporal_predictor_argument_checks_and_no_cpu_fallback():
         assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
 
 
+def test_temporal_team_size_rule():
+    """host arithmetic of dp_temporal_predict's kernel choice (dp_temporal.hip: teams of workgroups per sequence when there are few): every member on a
+    CU of its own, at least one feed-forward tile per wave, 16 up to a quarter of the device"""
+    lib = _lib.load()
+    size = lambda n_seq, n_cu=256, ff=2048: lib.dp_temporal_debug_team_size(n_cu, n_seq, ff)
+    assert [size(s) for s in (1, 4, 5, 16, 32, 33, 64, 65, 128, 129, 256, 1024)] == [16, 16, 8, 8, 8, 4, 4, 2, 2, 1, 1, 1]
+    for s in range(1, 300):
+        g = size(s)
+        assert g in (1, 2, 4, 8, 16) and (g == 1 or s * g <= 256)
+    assert size(1, ff=200) == 1 and size(1, ff=256) == 2 and size(1, ff=1024) == 8  # (13 / 16 / 64 tiles: a tile per wave of every member)
+    assert size(1, n_cu=8) == 8 and size(3, n_cu=8) == 2 and size(5, n_cu=8) == 1 and size(0) == 1
+
+
 def test_rotation_target_validation():
     """LatentOptimizer.optimize(validate_targets=True) -> check_rotation_targets: the kernels evaluate |R - T|^2 in its quaternion
     form, equal to the reference's element-wise form only for rotation matrices (include/dragposer.h: dp_batch.tgt_rot)"""
