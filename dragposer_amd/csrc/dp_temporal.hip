@@ -30,8 +30,14 @@ constexpr int MAXT = DP_TEMPORAL_MAX_TOKENS, MAXL = DP_TEMPORAL_MAX_LAYERS;
 constexpr int NT = 512, NWV = NT / 64;              // threads / waves per workgroup (two waves per SIMD)
 constexpr int LN_MAX = (MAXL * 4 + MAXL * 6 + 4) * D;  // floats of the LayerNorm block at the largest architecture
 constexpr int MAX_IN = 36;                          // 24 + 3 + 8 heights, padded to a multiple of 4 (K-steps)
-constexpr int FFN_TILE_FLOATS = 7 * 64 * 4;         // packed feed-forward weights of one 16-unit tile: 7 float4 per lane
+constexpr int FT = 32;                              // hidden units per feed-forward tile (the K of one v_mfma_f32_16x16x32_bf16)
+constexpr int FFN_IMG_V = 12 + 9 + 2;               // 16-byte words per lane of a tile's image: W1 [2 M-tiles][2 K-blocks][3 terms], W2 [3 column tiles][3 terms], bias1 [2]
+constexpr int FFN_TILE_FLOATS = FFN_IMG_V * 64 * 4; // ... in 32-bit words
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 
 struct TLayer { // offsets (in floats) into the device weight buffer
     int sa_in_wT, sa_in_b, sa_out_wT, sa_out_b, ca_in_wT, ca_in_b, ca_out_wT, ca_out_b;
@@ -315,7 +321,9 @@ template <int NS>
 DEV void attention(float* ao, const float* q, const float* k, const float* v, float* sc, int Tq, int Tk)
 {
     const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (as in lin)
+    const int wave = threadIdx.x >> 6;
     const int h = wave & (NHD - 1), sq = NS == 1 ? 0 : wave / NHD; // NS = 1: waves h and h + 4 share head h; NS = 2: wave = 4 * sequence + head
     constexpr int SHARE = NS == 1 ? NWV / NHD : 1;                  // waves per (sequence, head)
     const int part = NS == 1 ? wave / NHD : 0;
@@ -461,48 +469,141 @@ template <int GG> DEV void gather(float (&sum)[3], const f4* src, Team* tm)
     }
 }
 
-// one tile of 16 hidden units: H^T = W1 X^T (12 MFMAs), bias + ReLU, OUT += H W2^T (12 MFMAs; the first product's
-// accumulator is the second's A operand)
-DEV void ffn_tile(const f4 (&im)[7], const float (&xb)[D / 4], f4 (&acc)[3])
+// ---- the feed-forward block in SPLIT PRECISION on the bf16 matrix pipe (round 5; the arithmetic of dp_w16.h) -------------------------------
+// 94 % of the block's FLOPs are the two products of the feed-forward layers; on v_mfma_f32_16x16x4_f32 they kept the matrix pipe -- and with it,
+// fp32 MFMAs and the vector ALU being ONE issue resource on gfx950, the whole SIMD -- busy for 2/3 of the kernel at 1024 sequences (an ablation
+// with half of them: -34 %).  v_mfma_f32_16x16x32_bf16 retires K = 32 per 16 cycles and leaves the vector ALU to the other waves.  Every fp32
+// operand -- weight or activation -- is the exact sum of three bf16 terms (round-to-nearest at every stage, the remainders exact fp32 differences),
+// and a product keeps the six term pairs above 2^-24 relative (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), accumulated in fp32 by the MFMA: an fp32
+// product up to its last bit or two.  A tile = 32 hidden units:
+//   product 1  H^T[16 hidden x 16 tokens] (two M-tiles) = W1[16 x 64] X^T[64 x 16]: A = the weight rows (terms split by the host), B = the tokens'
+//              channels (48, padded to two K-blocks of 32; split ONCE per call into LDS, split_tokens) -- 2 x 2 x 6 = 24 MFMAs;
+//   bias + ReLU in registers; lane (token l16, group g) holds hidden units 4 g + r of both M-tiles: EIGHT values = its K-slots j = 4 t + r of
+//   product 2  OUT[16 tokens x 16 columns] (three column tiles) += H[16 x 32] W2^T[32 x 16]: A = the three terms of those eight values (split in
+//              registers: no LDS, no transposition), B = the weight terms, K-slot (g, j) = hidden unit 16 (j >> 2) + 4 g + (j & 3) by the host's
+//              packing -- 3 x 6 = 18 MFMAs.  The result layout is the fp32 kernel's (lane = column l16 of tile ct, register r = token 4 g + r).
+// 42 MFMAs of 16 cycles per 32 hidden units and token tile, where the fp32 form took 48 of 32.
+DEV unsigned cvt_pk(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{lo, hi}, bf2)); }
+DEV void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l)
+{ // x = h + m + l exactly
+    h = cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk(s0, s1);
+}
+struct T3 { u4 t[3]; }; // the three bf16 terms of eight values (one lane's share of a K-block)
+DEV T3 split_block(f4 t0, f4 t1)
 {
-    f4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+    unsigned h[4], m[4], l[4];
+    split_pair(t0.x, t0.y, h[0], m[0], l[0]);
+    split_pair(t0.z, t0.w, h[1], m[1], l[1]);
+    split_pair(t1.x, t1.y, h[2], m[2], l[2]);
+    split_pair(t1.z, t1.w, h[3], m[3], l[3]);
+    T3 b;
+    b.t[0] = u4{h[0], h[1], h[2], h[3]};
+    b.t[1] = u4{m[0], m[1], m[2], m[3]};
+    b.t[2] = u4{l[0], l[1], l[2], l[3]};
+    return b;
+}
+DEV f4 mm(u4 a, u4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0); }
+DEV f4 six(f4 acc, const u4 (&a)[3], const u4 (&b)[3])
+{ // acc += A B over one K-block: the six term pairs, small ones first
+    acc = mm(a[2], b[0], acc);
+    acc = mm(a[1], b[1], acc);
+    acc = mm(a[0], b[2], acc);
+    acc = mm(a[1], b[0], acc);
+    acc = mm(a[0], b[1], acc);
+    acc = mm(a[0], b[0], acc);
+    return acc;
+}
+
+// the tokens of a call as product 1's B operand, once per call: xs[(token tile * 2 + K-block) * 3 + term][lane (token l16, group g)] = the terms of
+// channels 32 kb + 8 g .. + 7 of that token (zero beyond channel 47 and for rows without a token).  Every thread of the workgroup; ends with a barrier.
+template <int NS>
+DEV void split_tokens(u4* xs, const float* x, int T, int R)
+{
+    const int ntt = n_ttiles<NS>(T, R);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid)); // (as in lin: the per-thread addresses are recomputed per call, not hoisted out of the layer loops and held)
+    for (int item = tid; item < ntt * 2 * 64; item += NT) {
+        const int tt = item >> 7, kb = (item >> 6) & 1, ls = item & 63, l16 = ls & 15, g = ls >> 4, ch = 32 * kb + 8 * g;
+        f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (ch < D && row_valid<NS>(16 * tt + l16, T, R)) {
+            v0 = *(const f4*)(x + (16 * tt + l16) * D + ch);
+            v1 = *(const f4*)(x + (16 * tt + l16) * D + ch + 4);
+        }
+        const T3 b = split_block(v0, v1);
 #pragma unroll
-    for (int ks = 0; ks < D / 4; ks += 2) {
-        h0 = mfma(im[ks >> 2][ks & 3], xb[ks], h0);
-        h1 = mfma(im[(ks + 1) >> 2][(ks + 1) & 3], xb[ks + 1], h1);
+        for (int k = 0; k < 3; ++k) xs[((tt * 2 + kb) * 3 + k) * 64 + ls] = b.t[k];
     }
-    f4 h;
+    __syncthreads();
+}
+
+// a tile's image, one lane's share (FFN_IMG_V 16-byte words; pack layout in dp_temporal_create), in the parts the products read
+struct FW1 { u4 w[2][3]; f4 b1; };       // product 1, ONE M-tile (16 hidden units): [K-block][term], bias row
+struct FW2 { u4 w[3][3]; };              // product 2: [column tile][term]
+DEV void ffn_load1(FW1& im, const u4* img, int nt, int ntiles, int t)
+{ // (img: the layer's image + lane; t: the M-tile, a compile-time constant at every call)
+    if (nt < ntiles) {
+        const u4* p = img + (size_t)nt * FFN_IMG_V * 64;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = fmaxf(h0[r] + h1[r] + im[6][r], 0.f); // hidden unit 16 nt + 4 q + r, token l16
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) { const int i = 3 * r + ct; acc[ct] = mfma(h[r], im[3 + (i >> 2)][i & 3], acc[ct]); }
+            for (int k = 0; k < 3; ++k) im.w[kb][k] = p[((t * 2 + kb) * 3 + k) * 64];
+        im.b1 = __builtin_bit_cast(f4, p[(21 + t) * 64]);
     }
 }
-DEV void ffn_load(f4 (&im)[7], const f4* img, int nt, int ntiles)
+DEV void ffn_load2(FW2& im, const u4* img, int nt, int ntiles)
 {
     if (nt < ntiles) {
+        const u4* p = img + (size_t)nt * FFN_IMG_V * 64;
 #pragma unroll
-        for (int v = 0; v < 7; ++v) im[v] = img[((size_t)nt * 7 + v) * 64];
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) im.w[ct][k] = p[(12 + ct * 3 + k) * 64];
     }
+}
+// product 1 of one M-tile (16 hidden units) on one token tile, bias, ReLU: lane (token l16, group g) gets hidden units 4 g + r of the M-tile.
+// xs = that token tile's operand rows in LDS (+ lane)
+DEV f4 ffn_p1(const FW1& im, const u4* xs)
+{
+    f4 h = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const u4 xb[3] = {xs[(kb * 3 + 0) * 64], xs[(kb * 3 + 1) * 64], xs[(kb * 3 + 2) * 64]};
+        h = six(h, im.w[kb], xb);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r] + im.b1[r], 0.f);
+    return h;
+}
+// product 2: the two M-tiles' values are the lane's eight K-slots; their three terms are made here (kept as fp32 until now: 8 registers, not 12)
+DEV void ffn_p2(const FW2& im, f4 h0, f4 h1, f4 (&acc)[3])
+{
+    const T3 ht = split_block(h0, h1);
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) acc[ct] = six(acc[ct], ht.t, im.w[ct]);
 }
 
 // o[t] = linear2(relu(linear1(x[t]))) + bias2  (header comment; pack layout in dp_temporal_create).
-// PREFETCH: a wave keeps the images of three tiles in flight (84 registers: the one-workgroup-per-CU kernel, where a SIMD
-// has two waves to hide an L2 round trip behind 768 cycles of MFMA per tile); otherwise one, and four waves per SIMD.
+// (PREFETCH: no longer a difference in the feed-forward -- every variant passes a tile's image through the registers in two parts.)
 // NS = 2: every tile image serves the token tiles of both sequences.
 // TEAM (NS = 1): workgroup g of G takes the tiles g * 8 + wave, + 8 G, ...; its eight waves' partial outputs are summed through LDS as ever, the G
 // workgroups' sums are exchanged as granules (above) and every workgroup adds them up in the same order -- all G hold the same `o` afterwards,
 // bit for bit, which is what lets them run the rest of the block redundantly and in step.
 template <bool PREFETCH, int NS, int R = 16, bool TEAM = false>
-DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red, Team* tm = nullptr, const f4 (*pre)[7] = nullptr)
-{ // (pre: TEAM -- the image of this wave's first tile, requested by the caller at the head of the layer: a cold fetch hidden behind the attention) // (R, the rows per sequence, is a compile-time constant here: as a run-time value it cost the 128-register instantiation 8 spills)
+DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red, u4* xsb, Team* tm = nullptr, const FW1* pre = nullptr)
+{ // (xsb: LDS for the tokens' operand rows -- the attention's score buffer, idle here; pre: TEAM -- the image of this wave's first tile, requested by
+  //  the caller at the head of the layer: a cold fetch hidden behind the attention; R, the rows per sequence, is a compile-time constant here: as a
+  //  run-time value it cost the 128-register instantiation 8 spills)
+    split_tokens<NS>(xsb, x, T, R);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
-    const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
-    const int ntiles = (F + 15) >> 4;
-    const f4* img = (const f4*)(w + pack) + lane;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = (F + FT - 1) / FT;
+    const u4* img = (const u4*)(w + pack) + lane;
+    const u4* xs = xsb + lane;
     constexpr int NG = NS == 1 ? 1 : (NS * R + 15) / 16; // token tiles that share one pass over the weights (R = 8: ONE tile for the two sequences)
     const int ntt = n_ttiles<NS>(T, R);
     const int first = TEAM ? tm->g * NWV + wave : wave, stride = TEAM ? tm->G * NWV : NWV; // this wave's tiles
@@ -511,60 +612,50 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 #pragma unroll 1
     for (int tt0 = 0; tt0 < ntt; tt0 += NG) {
         constexpr int ng = NG;
-        float xb[NG][D / 4]; // B operand of the first product: X^T[k][token]
         f4 acc[NG][3];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const bool rv = g < ng && row_valid<NS>(16 * (tt0 + g) + l16, T, R);
-#pragma unroll
-            for (int ks = 0; ks < D / 4; ++ks) xb[g][ks] = rv ? x[(16 * (tt0 + g) + l16) * D + 4 * ks + q] : 0.f;
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (TEAM) { // (at most 16 / G tiles per wave: two images in flight, the first one requested by the caller)
-            f4 b0[7], b1[7];
+        // a tile's image goes through the registers in parts: product 1's two M-tiles, product 2.  256 registers (PREFETCH, TEAM): product 2's part is
+        // in flight under product 1, the NEXT tile's under product 2 (TEAM: the first tile's first M-tile was requested by the caller at the head of
+        // the layer).  128 registers: one part at a time, requested when the registers are free (the three other waves of the SIMD cover the round trip).
+        if (TEAM || PREFETCH) {
+            FW1 w1a, w1b;
+            FW2 w2;
             int nt = first;
-            if (pre) {
-#pragma unroll
-                for (int v = 0; v < 7; ++v) b0[v] = (*pre)[v];
-            } else ffn_load(b0, img, nt, ntiles);
+            if (TEAM && pre) w1a = *pre;
+            else ffn_load1(w1a, img, nt, ntiles, 0);
+            ffn_load1(w1b, img, nt, ntiles, 1);
+#pragma unroll 1
             while (nt < ntiles) {
-                ffn_load(b1, img, nt + stride, ntiles);
-                ffn_tile(b0, xb[0], acc[0]);
-                nt += stride;
-                if (nt >= ntiles) break;
-                ffn_load(b0, img, nt + stride, ntiles);
-                ffn_tile(b1, xb[0], acc[0]);
-                nt += stride;
-            }
-        } else if (PREFETCH) {
-            f4 b0[7], b1[7], b2[7];
-            int nt = first;
-            ffn_load(b0, img, nt, ntiles);
-            ffn_load(b1, img, nt + stride, ntiles);
-            while (nt < ntiles) {
-                ffn_load(b2, img, nt + 2 * stride, ntiles);
+                ffn_load2(w2, img, nt, ntiles);
+                f4 h[NG][2];
 #pragma unroll
-                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b0, xb[g], acc[g]);
-                nt += stride;
-                if (nt >= ntiles) break;
-                ffn_load(b0, img, nt + 2 * stride, ntiles);
+                for (int g = 0; g < NG; ++g) if (g < ng) { h[g][0] = ffn_p1(w1a, xs + (tt0 + g) * 6 * 64); h[g][1] = ffn_p1(w1b, xs + (tt0 + g) * 6 * 64); }
+                ffn_load1(w1a, img, nt + stride, ntiles, 0);
+                ffn_load1(w1b, img, nt + stride, ntiles, 1);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b1, xb[g], acc[g]);
-                nt += stride;
-                if (nt >= ntiles) break;
-                ffn_load(b1, img, nt + 2 * stride, ntiles);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(b2, xb[g], acc[g]);
+                for (int g = 0; g < NG; ++g) if (g < ng) ffn_p2(w2, h[g][0], h[g][1], acc[g]);
                 nt += stride;
             }
         } else {
 #pragma unroll 1
             for (int nt = first; nt < ntiles; nt += stride) {
-                f4 cur[7];
-                ffn_load(cur, img, nt, ntiles);
+                f4 h[NG][2];
 #pragma unroll
-                for (int g = 0; g < NG; ++g) if (g < ng) ffn_tile(cur, xb[g], acc[g]);
+                for (int t = 0; t < 2; ++t) {
+                    FW1 w1;
+                    ffn_load1(w1, img, nt, ntiles, t);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) if (g < ng) h[g][t] = ffn_p1(w1, xs + (tt0 + g) * 6 * 64);
+                    __builtin_amdgcn_sched_barrier(0); // (the next part's loads are not to be hoisted above this one's products: registers)
+                }
+                FW2 w2;
+                ffn_load2(w2, img, nt, ntiles);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ng) ffn_p2(w2, h[g][0], h[g][1], acc[g]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP(23);
@@ -703,14 +794,14 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     STAMP(11);
     for (int l = 0; l < a.n_enc; ++l) {
         const TLayer L = layer_of(l);
-        f4 pre[7];
-        if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
+        FW1 pre;
+        if constexpr (TEAM) ffn_load1(pre, (const u4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + FT - 1) / FT, 0);
         mha<NS>(o, x, Te, x, Te, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
         add_ln<NS>(x, o, Te, wl + L.n1w, wl + L.n1b);
         STAMP(4);
-        if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, &team, &pre);
-        else if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform; a history of at most 8 tokens)
-        else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red);
+        if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc, &team, &pre);
+        else if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc); // (uniform; a history of at most 8 tokens)
+        else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc);
         STAMP(5);
         add_ln<NS>(x, o, Te, wl + L.n2w, wl + L.n2b);
         STAMP(4);
@@ -729,17 +820,17 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         STAMP(13);
         for (int l = 0; l < a.n_dec; ++l) {
             const TLayer L = layer_of(a.n_enc + l);
-            f4 pre[7];
-            if constexpr (TEAM) ffn_load(pre, (const f4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + 15) >> 4);
+            FW1 pre;
+            if constexpr (TEAM) ffn_load1(pre, (const u4*)(w + L.ffn_pack) + (tid & 63), team.g * NWV + (tid >> 6), (a.ff + FT - 1) / FT, 0);
             mha<NS>(o, x, T, x, T, w, L.sa_in_wT, L.sa_in_b, L.sa_out_wT, L.sa_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, wl + L.n1w, wl + L.n1b);
             STAMP(4);
             mha<NS>(o, x, T, mem, Te, w, L.ca_in_wT, L.ca_in_b, L.ca_out_wT, L.ca_out_b, q, kb, vb, ao, sc);
             add_ln<NS>(x, o, T, wl + L.n2w, wl + L.n2b);
             STAMP(4);
-            if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, &team, &pre);
-            else if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red); // (uniform)
-            else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red);
+            if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc, &team, &pre);
+            else if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc); // (uniform)
+            else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc);
             STAMP(5);
             add_ln<NS>(x, o, T, wl + L.n3w, wl + L.n3b);
             STAMP(4);
@@ -814,33 +905,66 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
             for (int c = 0; c < cols_in; ++c) buf[off + (size_t)r * ldk + c] = p[(size_t)r * cols_in + c];
         return off;
     };
-    // feed-forward image, per tile of 16 hidden units and lane (token / channel l16 = lane & 15, q = lane >> 4), 7 float4:
-    //   v = 0..2: W1[16 nt + l16][4 ks + q], ks = 4 v + e          (A operand of H^T = W1 X^T, K-step ks)
-    //   v = 3..5: W2[16 ct + l16][16 nt + 4 q + r], 3 r + ct = 4 (v - 3) + e   (B operand of OUT += H W2^T: K-step r, slot q)
-    //   v = 6:    bias1[16 nt + 4 q + e]
-    // hidden units beyond F are zero rows / columns (ReLU(0) = 0 contributes nothing)
+    // feed-forward image (split precision: the comment above ffn_tile), per tile of 32 hidden units and lane (l16 = lane & 15, g = lane >> 4),
+    // FFN_IMG_V 16-byte words of eight bf16 each (element j in bits 16 (j & 1) of word j >> 1), three words per operand = its hi / mid / lo terms:
+    //   v = (t 2 + kb) 3 + term:      W1[32 nt + 16 t + l16][32 kb + 8 g + j]                          (A of product 1: M-tile t, K-block kb)
+    //   v = 12 + ct 3 + term:         W2[16 ct + l16][32 nt + 16 (j >> 2) + 4 g + (j & 3)]             (B of product 2: column tile ct)
+    //   v = 21 + t (four floats):     bias1[32 nt + 16 t + 4 g + r]
+    // hidden units beyond F and input channels beyond 47 are zeros (ReLU(0) = 0 contributes nothing)
+    auto bf16_rne = [](float x) -> unsigned { // float -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does; weights are finite)
+        unsigned u;
+        std::memcpy(&u, &x, 4);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    auto bf16_val = [](unsigned h) { const unsigned u = h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    auto split3 = [&](float x, unsigned (&t)[3]) { // x = t0 + t1 + t2 exactly (the device's split_pair)
+        t[0] = bf16_rne(x);
+        const float r = x - bf16_val(t[0]);
+        t[1] = bf16_rne(r);
+        const float q = r - bf16_val(t[1]);
+        t[2] = bf16_rne(q);
+    };
     auto pack_ffn = [&](const float* w1, const float* b1, const float* w2) {
-        while (buf.size() % 4) buf.push_back(0.f); // 16-byte alignment of the float4 image
-        const int off = (int)buf.size(), ntiles = (F + 15) / 16;
+        while (buf.size() % 4) buf.push_back(0.f); // 16-byte alignment of the image
+        const int off = (int)buf.size(), ntiles = (F + FT - 1) / FT;
         buf.resize(buf.size() + (size_t)ntiles * FFN_TILE_FLOATS, 0.f);
         if (!w1 || !b1 || !w2) { null_seen = true; return off; }
         for (int nt = 0; nt < ntiles; ++nt)
             for (int lane = 0; lane < 64; ++lane) {
-                const int l16 = lane & 15, q = lane >> 4;
+                const int l16 = lane & 15, g = lane >> 4;
                 float* dst = buf.data() + off + (size_t)nt * FFN_TILE_FLOATS;
-                auto at = [&](int v, int e) -> float& { return dst[(v * 64 + lane) * 4 + e]; };
-                for (int ks = 0; ks < D / 4; ++ks) {
-                    const int n = 16 * nt + l16;
-                    at(ks >> 2, ks & 3) = n < F ? w1[(size_t)n * D + 4 * ks + q] : 0.f;
-                }
-                for (int r = 0; r < 4; ++r) {
-                    const int n = 16 * nt + 4 * q + r;
-                    for (int ct = 0; ct < 3; ++ct) {
-                        const int i = 3 * r + ct;
-                        at(3 + (i >> 2), i & 3) = n < F ? w2[(size_t)(16 * ct + l16) * F + n] : 0.f;
+                auto put8 = [&](int v0, const float (&val)[8]) { // eight values -> the words v0 (hi), v0 + 1 (mid), v0 + 2 (lo) of this lane
+                    unsigned words[3][4] = {};
+                    for (int j = 0; j < 8; ++j) {
+                        unsigned t[3];
+                        split3(val[j], t);
+                        for (int k = 0; k < 3; ++k) words[k][j >> 1] |= t[k] << (16 * (j & 1));
                     }
-                    at(6, r) = n < F ? b1[n] : 0.f;
+                    for (int k = 0; k < 3; ++k) std::memcpy(dst + ((v0 + k) * 64 + lane) * 4, words[k], 16);
+                };
+                for (int t = 0; t < 2; ++t)
+                    for (int kb = 0; kb < 2; ++kb) {
+                        float val[8];
+                        const int h = FT * nt + 16 * t + l16;
+                        for (int j = 0; j < 8; ++j) {
+                            const int c = 32 * kb + 8 * g + j;
+                            val[j] = (h < F && c < D) ? w1[(size_t)h * D + c] : 0.f;
+                        }
+                        put8((t * 2 + kb) * 3, val);
+                    }
+                for (int ct = 0; ct < 3; ++ct) {
+                    float val[8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int h = FT * nt + 16 * (j >> 2) + 4 * g + (j & 3);
+                        val[j] = h < F ? w2[(size_t)(16 * ct + l16) * F + h] : 0.f;
+                    }
+                    put8(12 + ct * 3, val);
                 }
+                for (int t = 0; t < 2; ++t)
+                    for (int r = 0; r < 4; ++r) {
+                        const int h = FT * nt + 16 * t + 4 * g + r;
+                        dst[((21 + t) * 64 + lane) * 4 + r] = h < F ? b1[h] : 0.f;
+                    }
             }
         return off;
     };
@@ -966,7 +1090,7 @@ extern "C" int dp_temporal_debug_team_size(int n_cu, int n_seq, int dim_feedforw
 {
     if (n_cu <= 0 || n_seq <= 0 || dim_feedforward <= 0) return 1;
     int G = 1;
-    while (G < 16 && n_seq * (2 * G) <= n_cu && (dim_feedforward + 15) / 16 >= 2 * G * NWV) G *= 2;
+    while (G < 16 && n_seq * (2 * G) <= n_cu && (dim_feedforward + FT - 1) / FT >= 2 * G * NWV) G *= 2;
     if (G == 16 && n_seq * 64 > n_cu) G = 8;
     return G;
 }
@@ -1008,7 +1132,7 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     int G = dp_temporal_debug_team_size(t->n_cu, n_seq, m.ff);
     if (t->forced_variant >= 100) { // (a forced size: the largest the launch fits, whatever pays)
         G = 1;
-        while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + 15) / 16 >= 2 * G * NWV) G *= 2;
+        while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + FT - 1) / FT >= 2 * G * NWV) G *= 2;
     }
     if (t->forced_variant >= 100) { const int want = t->forced_variant - 100; G = G >= want ? want : 1; }
     if (G >= 2 && (t->forced_variant == 0 || t->forced_variant >= 100)) variant = 100 + G;
