@@ -476,13 +476,15 @@ template <int GG> DEV void gather(float (&sum)[3], const f4* src, Team* tm)
 // operand -- weight or activation -- is the exact sum of three bf16 terms (round-to-nearest at every stage, the remainders exact fp32 differences),
 // and a product keeps the six term pairs above 2^-24 relative (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), accumulated in fp32 by the MFMA: an fp32
 // product up to its last bit or two.  A tile = 32 hidden units:
-//   product 1  H^T[16 hidden x 16 tokens] (two M-tiles) = W1[16 x 64] X^T[64 x 16]: A = the weight rows (terms split by the host), B = the tokens'
-//              channels (48, padded to two K-blocks of 32; split ONCE per call into LDS, split_tokens) -- 2 x 2 x 6 = 24 MFMAs;
+//   product 1  H^T[16 hidden x 16 tokens] (two M-tiles) = W1[16 x 48] X^T[48 x 16]: A = the weight rows (terms split by the host), B = the tokens'
+//              channels (split ONCE per call into LDS, split_tokens).  Channels 0 .. 31 are one K-block: six MFMAs.  Channels 32 .. 47 are half
+//              a K-block, so each of their MFMAs carries TWO term pairs -- slots 0 .. 15 one, slots 16 .. 31 another: A = [hi | hi], [mid | mid],
+//              [lo | hi] against B = [hi | mid], [hi | mid], [hi | lo] -- three MFMAs, not six: 2 x 9 = 18 MFMAs;
 //   bias + ReLU in registers; lane (token l16, group g) holds hidden units 4 g + r of both M-tiles: EIGHT values = its K-slots j = 4 t + r of
 //   product 2  OUT[16 tokens x 16 columns] (three column tiles) += H[16 x 32] W2^T[32 x 16]: A = the three terms of those eight values (split in
 //              registers: no LDS, no transposition), B = the weight terms, K-slot (g, j) = hidden unit 16 (j >> 2) + 4 g + (j & 3) by the host's
 //              packing -- 3 x 6 = 18 MFMAs.  The result layout is the fp32 kernel's (lane = column l16 of tile ct, register r = token 4 g + r).
-// 42 MFMAs of 16 cycles per 32 hidden units and token tile, where the fp32 form took 48 of 32.
+// 36 MFMAs of 16 cycles per 32 hidden units and token tile, where the fp32 form took 48 of 32.
 DEV unsigned cvt_pk(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{lo, hi}, bf2)); }
 DEV void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l)
 { // x = h + m + l exactly
@@ -518,24 +520,33 @@ DEV f4 six(f4 acc, const u4 (&a)[3], const u4 (&b)[3])
     return acc;
 }
 
-// the tokens of a call as product 1's B operand, once per call: xs[(token tile * 2 + K-block) * 3 + term][lane (token l16, group g)] = the terms of
-// channels 32 kb + 8 g .. + 7 of that token (zero beyond channel 47 and for rows without a token).  Every thread of the workgroup; ends with a barrier.
+// the tokens of a call as product 1's B operand, once per call, five rows of 64 lanes x 16 bytes per token tile (stride six): rows 0 .. 2 = the
+// hi / mid / lo terms of channels 8 g .. 8 g + 7 of token l16 (lane = (l16, g)); row 3 = [hi | mid], row 4 = [hi | lo] of channels 32 .. 47
+// (lanes g < 2: the first term of channels 32 + 8 g ..; lanes g >= 2: the second term of channels 32 + 8 (g - 2) ..).  Zero for rows without a
+// token.  Every thread of the workgroup; ends with a barrier.
 template <int NS>
 DEV void split_tokens(u4* xs, const float* x, int T, int R)
 {
     const int ntt = n_ttiles<NS>(T, R);
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // (as in lin: the per-thread addresses are recomputed per call, not hoisted out of the layer loops and held)
-    for (int item = tid; item < ntt * 2 * 64; item += NT) {
-        const int tt = item >> 7, kb = (item >> 6) & 1, ls = item & 63, l16 = ls & 15, g = ls >> 4, ch = 32 * kb + 8 * g;
+    for (int item = tid; item < ntt * 96; item += NT) { // per token tile: 64 lane slots of the full K-block, 32 of the half one
+        const int tt = item / 96, r = item - tt * 96, l16 = r & 15, g = r >> 4, ch = 8 * g; // g = 0 .. 3: channels 0 .. 31; g = 4, 5: channels 32 .. 47
         f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        if (ch < D && row_valid<NS>(16 * tt + l16, T, R)) {
+        if (row_valid<NS>(16 * tt + l16, T, R)) {
             v0 = *(const f4*)(x + (16 * tt + l16) * D + ch);
             v1 = *(const f4*)(x + (16 * tt + l16) * D + ch + 4);
         }
         const T3 b = split_block(v0, v1);
+        u4* row = xs + tt * 6 * 64;
+        if (g < 4) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xs[((tt * 2 + kb) * 3 + k) * 64 + ls] = b.t[k];
+            for (int k = 0; k < 3; ++k) row[k * 64 + 16 * g + l16] = b.t[k];
+        } else {
+            const int ls = 16 * (g - 4) + l16;
+            row[3 * 64 + ls] = b.t[0]; row[3 * 64 + 32 + ls] = b.t[1];
+            row[4 * 64 + ls] = b.t[0]; row[4 * 64 + 32 + ls] = b.t[2];
+        }
     }
     __syncthreads();
 }
@@ -569,10 +580,15 @@ DEV void ffn_load2(FW2& im, const u4* img, int nt, int ntiles)
 DEV f4 ffn_p1(const FW1& im, const u4* xs)
 {
     f4 h = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const u4 xb[3] = {xs[(kb * 3 + 0) * 64], xs[(kb * 3 + 1) * 64], xs[(kb * 3 + 2) * 64]};
-        h = six(h, im.w[kb], xb);
+    { // channels 32 .. 47: two term pairs per MFMA (small ones first)
+        const u4 b1 = xs[3 * 64], b3 = xs[4 * 64];
+        h = mm(im.w[1][2], b3, h); // lo.hi + hi.lo
+        h = mm(im.w[1][1], b1, h); // mid.hi + mid.mid
+        h = mm(im.w[1][0], b1, h); // hi.hi + hi.mid
+    }
+    {
+        const u4 xb[3] = {xs[0], xs[64], xs[2 * 64]};
+        h = six(h, im.w[0], xb);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r] + im.b1[r], 0.f);
@@ -907,7 +923,9 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     };
     // feed-forward image (split precision: the comment above ffn_tile), per tile of 32 hidden units and lane (l16 = lane & 15, g = lane >> 4),
     // FFN_IMG_V 16-byte words of eight bf16 each (element j in bits 16 (j & 1) of word j >> 1), three words per operand = its hi / mid / lo terms:
-    //   v = (t 2 + kb) 3 + term:      W1[32 nt + 16 t + l16][32 kb + 8 g + j]                          (A of product 1: M-tile t, K-block kb)
+    //   v = (t 2) 3 + term:           W1[32 nt + 16 t + l16][8 g + j]                                  (A of product 1: M-tile t, channels 0 .. 31)
+    //   v = (t 2 + 1) 3 + {0, 1, 2}:  [hi | hi], [mid | mid], [lo | hi] of W1[32 nt + 16 t + l16][32 + 8 (g & 1) + j]: the first term in lanes g < 2,
+    //                                 the second in lanes g >= 2                                       (channels 32 .. 47: two term pairs per MFMA)
     //   v = 12 + ct 3 + term:         W2[16 ct + l16][32 nt + 16 (j >> 2) + 4 g + (j & 3)]             (B of product 2: column tile ct)
     //   v = 21 + t (four floats):     bias1[32 nt + 16 t + 4 g + r]
     // hidden units beyond F and input channels beyond 47 are zeros (ReLU(0) = 0 contributes nothing)
@@ -942,16 +960,21 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
                     }
                     for (int k = 0; k < 3; ++k) std::memcpy(dst + ((v0 + k) * 64 + lane) * 4, words[k], 16);
                 };
-                for (int t = 0; t < 2; ++t)
-                    for (int kb = 0; kb < 2; ++kb) {
-                        float val[8];
-                        const int h = FT * nt + 16 * t + l16;
-                        for (int j = 0; j < 8; ++j) {
-                            const int c = 32 * kb + 8 * g + j;
-                            val[j] = (h < F && c < D) ? w1[(size_t)h * D + c] : 0.f;
-                        }
-                        put8((t * 2 + kb) * 3, val);
+                for (int t = 0; t < 2; ++t) {
+                    float val[8];
+                    const int h = FT * nt + 16 * t + l16;
+                    for (int j = 0; j < 8; ++j) val[j] = h < F ? w1[(size_t)h * D + 8 * g + j] : 0.f;
+                    put8((t * 2) * 3, val);
+                    // channels 32 .. 47: which TERM a lane holds depends on its half of the K-block
+                    unsigned words[3][4] = {};
+                    for (int j = 0; j < 8; ++j) {
+                        unsigned tm[3];
+                        split3(h < F ? w1[(size_t)h * D + 32 + 8 * (g & 1) + j] : 0.f, tm);
+                        const unsigned pick[3] = {tm[0], tm[1], g < 2 ? tm[2] : tm[0]}; // [hi | hi], [mid | mid], [lo | hi]
+                        for (int k = 0; k < 3; ++k) words[k][j >> 1] |= pick[k] << (16 * (j & 1));
                     }
+                    for (int k = 0; k < 3; ++k) std::memcpy(dst + (((t * 2 + 1) * 3 + k) * 64 + lane) * 4, words[k], 16);
+                }
                 for (int ct = 0; ct < 3; ++ct) {
                     float val[8];
                     for (int j = 0; j < 8; ++j) {
