@@ -3,19 +3,20 @@
 //
 // A torch.nn.Transformer (post-norm layers, ReLU, final encoder / decoder LayerNorm, no masks, dropout off) of width 48
 // over at most 32 tokens: far too small for one GPU to be busy with one sequence, so the unit of work is ONE WORKGROUP PER
-// SEQUENCE (or per two, when there are many: below) that runs the whole block -- token assembly from the history buffers, the encoder once, window / step + 1
+// SEQUENCE (or per two when there are many; a TEAM of up to eight per sequence when there are few: below) that runs the whole block -- token
+// assembly from the history buffers, the encoder once, window / step + 1
 // autoregressive decoder calls (the reference passes no target mask, so every call recomputes all target positions),
-// de-normalisation and the step-hold "lerp" -- with every activation in LDS and the weights (5 MB fp32 at the reference's
-// size) streamed from L2.  The small linear weights keep torch's [out][in] layout (rows padded to a multiple of four floats): a lane
-// reads a quarter of a row in 16-byte words (lin).
-// Every product runs on v_mfma_f32_16x16x4_f32 with the (at most 16, else tiled) tokens as one tile dimension:
-//   * linear layers: M = token, N = output channel, K = input channel; A from LDS, B one coalesced word per lane and K-step;
-//   * the feed-forward block (48 -> F -> 48, 94 % of the FLOPs and of the weight bytes), per tile of 16 hidden units:
-//     H^T = W1 X^T (M = hidden unit, N = token: 12 MFMAs), bias + ReLU in registers, then OUT += H W2^T with the
-//     accumulator of the first product AS the A operand of the second -- register r of lane (token, q) holds hidden unit
-//     4q + r of the tile, which is K-slot q of K-step r by definition of the packed W2 image (12 MFMAs, no LDS, no
-//     transposition).  The tiles are dealt to the 8 waves, weights arrive as 7 coalesced 16-byte loads per lane and tile
-//     (requested one tile ahead), the waves' partial outputs are summed through LDS.  fp32 throughout.
+// de-normalisation and the step-hold "lerp" -- with every activation in LDS and the weights (7.7 MB at the reference's
+// size) streamed from L2.
+//   * the small linear layers (in_proj, out_proj: 6 % of the FLOPs) on v_mfma_f32_16x16x4_f32, fp32: M = token, N = output channel, K = input
+//     channel; the weights keep torch's [out][in] layout (rows padded to a multiple of four floats), a lane reads a quarter of a row and of its
+//     token's activations in 16-byte words (lin);
+//   * the feed-forward block (48 -> F -> 48, 94 % of the FLOPs and of the weight bytes) on v_mfma_f32_16x16x32_bf16 in SPLIT PRECISION -- every
+//     fp32 operand the exact sum of three bf16 terms, six term products per K-block, fp32 accumulation: the arithmetic of an fp32 product to its
+//     last bit or two (dp_w16.h) -- per tile of 32 hidden units: H^T = W1 X^T, bias + ReLU in registers, then OUT += H W2^T with the first
+//     product's result AS the second's A operand (a lane's eight hidden units are its eight K-slots by the host's packing of W2: no LDS, no
+//     transposition).  The tiles are dealt to the 8 waves, a tile's image (weights already split: 21 + 2 sixteen-byte words per lane) passes
+//     through the registers in three parts, the waves' partial outputs are summed through LDS (see the comment above ffn_p1).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
