@@ -181,6 +181,8 @@ def load(path=None):
     lib.dp_temporal_debug_force_variant.argtypes = [C.c_void_p, C.c_int]
     lib.dp_temporal_debug_team_status.argtypes = [C.c_void_p]
     lib.dp_temporal_debug_team_size.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.dp_temporal_debug_split3.argtypes = [C.c_float, C.POINTER(C.c_ushort)]
+    lib.dp_temporal_debug_split3.restype = None
     lib.dp_debug_pack.argtypes = [C.POINTER(DpFolded), _i, _f, _f, C.POINTER(C.c_uint)]
     lib.dp_debug_items.argtypes = [C.POINTER(DpModel), C.c_void_p]
     lib.dp_debug_pack_w16.argtypes = [C.POINTER(DpFolded), C.POINTER(DpModel), C.c_void_p, C.c_void_p, C.c_void_p]

@@ -893,6 +893,37 @@ static int tfail(dp_temporal* t, int code, const std::string& msg)
     return code;
 }
 
+// float -> three bf16 terms with x = t0 + t1 + t2 exactly: the host's copy of the device's split_pair (round to nearest even at every stage, what
+// v_cvt_pk_bf16_f32 does; the remainders are exact fp32 differences).  Weights are finite.
+static unsigned host_bf16_rne(float x)
+{
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static float host_bf16_val(unsigned h)
+{
+    const unsigned u = h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+static void host_split3(float x, unsigned (&t)[3])
+{
+    t[0] = host_bf16_rne(x);
+    const float r = x - host_bf16_val(t[0]);
+    t[1] = host_bf16_rne(r);
+    const float q = r - host_bf16_val(t[1]);
+    t[2] = host_bf16_rne(q);
+}
+// private test hook (host arithmetic only; a CPU test holds it to numpy): the three bf16 terms of x as 16-bit patterns
+extern "C" void dp_temporal_debug_split3(float x, unsigned short* out3)
+{
+    unsigned t[3];
+    host_split3(x, t);
+    for (int k = 0; k < 3; ++k) out3[k] = (unsigned short)t[k];
+}
+
 extern "C" const char* dp_temporal_last_error(const dp_temporal* t) { return t ? t->err.c_str() : g_terr.c_str(); }
 
 extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m, int device)
@@ -930,19 +961,7 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     //   v = 12 + ct 3 + term:         W2[16 ct + l16][32 nt + 16 (j >> 2) + 4 g + (j & 3)]             (B of product 2: column tile ct)
     //   v = 21 + t (four floats):     bias1[32 nt + 16 t + 4 g + r]
     // hidden units beyond F and input channels beyond 47 are zeros (ReLU(0) = 0 contributes nothing)
-    auto bf16_rne = [](float x) -> unsigned { // float -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does; weights are finite)
-        unsigned u;
-        std::memcpy(&u, &x, 4);
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    };
-    auto bf16_val = [](unsigned h) { const unsigned u = h << 16; float f; std::memcpy(&f, &u, 4); return f; };
-    auto split3 = [&](float x, unsigned (&t)[3]) { // x = t0 + t1 + t2 exactly (the device's split_pair)
-        t[0] = bf16_rne(x);
-        const float r = x - bf16_val(t[0]);
-        t[1] = bf16_rne(r);
-        const float q = r - bf16_val(t[1]);
-        t[2] = bf16_rne(q);
-    };
+    auto split3 = [&](float x, unsigned (&t)[3]) { host_split3(x, t); };
     auto pack_ffn = [&](const float* w1, const float* b1, const float* w2) {
         while (buf.size() % 4) buf.push_back(0.f); // 16-byte alignment of the image
         const int off = (int)buf.size(), ntiles = (F + FT - 1) / FT;

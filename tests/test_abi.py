@@ -186,6 +186,35 @@ def test_temporal_team_size_rule():
     assert size(1, n_cu=8) == 8 and size(3, n_cu=8) == 2 and size(5, n_cu=8) == 1 and size(0) == 1
 
 
+def test_host_split_into_three_bf16_terms_is_exact():
+    """the feed-forward weights of the temporal predictor reach the bf16 matrix pipe as three bf16 terms each (dp_temporal.hip: split precision).
+    The host's split: every term the round-to-nearest-even bf16 of what is left, the three summing to the weight EXACTLY in fp32 arithmetic"""
+    import numpy as np
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.standard_normal(2000).astype(np.float32) * np.float32(0.2), np.float32([0.0, 1.0, -1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -9,
+                        1.0 + 3 * 2.0 ** -9, 3.0e-20, -7.5e11, 0.1, 2.0 ** -126])])
+    out = (C.c_ushort * 3)()
+
+    def val(h):
+        return np.array([int(h) << 16], dtype=np.uint32).view(np.float32)[0]
+
+    def rne(x):  # numpy restatement of the rounding
+        u = int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF
+
+    for x in xs:
+        lib.dp_temporal_debug_split3(float(x), out)
+        h, m, l = (int(out[k]) for k in range(3))
+        assert h == rne(x)
+        r = np.float32(x) - val(h)
+        assert m == rne(r)
+        q = np.float32(r) - val(m)
+        assert l == rne(q)
+        assert np.float32(np.float32(val(h) + val(m)) + val(l)) == np.float32(x) or abs(x) < 2.0 ** -100  # (8 + 8 + 8 significant bits cover fp32's 24)
+
+
 def test_rotation_target_validation():
     """LatentOptimizer.optimize(validate_targets=True) -> check_rotation_targets: the kernels evaluate |R - T|^2 in its quaternion
     form, equal to the reference's element-wise form only for rotation matrices (include/dragposer.h: dp_batch.tgt_rot)"""
