@@ -738,7 +738,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 }
 
 // OCC = waves per SIMD: 4 (two workgroups per CU, 128 registers: throughput with many sequences) or 2 (one workgroup per CU,
-// 256 registers, feed-forward weights prefetched three tiles deep: latency with few).  NS = sequences per workgroup.
+// 256 registers, the next part of a feed-forward tile's image in flight under the current one's products: latency with few).  NS = sequences per workgroup.
 // TEAM (OCC = 2, NS = 1; few sequences): a.G workgroups per sequence.  Every one of them runs the whole block -- same instructions, same data, same
 // bits -- except the feed-forward layers (94 % of the work), where each takes 1/G of the hidden units and the partial sums are exchanged (ffn).
 template <int OCC, int NS, bool TEAM = false>
