@@ -308,7 +308,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed_pass(batch, kernel, steps, warmup):
+    def timed_pass(batch, kernel, steps, warmup, from_idle=False):
         """W untimed warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize on both sides.  Ahead of the warm-up the
         device is PRECONDITIONED: the same launch back to back for --precondition-ms of GPU time.  Why: the shader clock is a DVFS state --
         2.08 GHz on the first launches after idle, 2.14 after ~3 ms, the 2.38-2.40 GHz plateau after ~25 ms of sustained load, back down
@@ -319,6 +319,17 @@ def main():
         torch.cuda.synchronize()
         # (the step as a caller that reuses its buffers issues it: arguments marshalled once, LatentOptimizer.plan -- one dp_optimize call per step)
         step = opt.plan(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
+        # what a caller who submits ONE batch to an idle GPU gets: after >= 100 ms without work, one launch between two events, read back with the
+        # clock it ran at (the DVFS floor, 2.08-2.10 GHz).  Reported beside the steady figures (roofline.*_from_idle); never part of `value`.
+        idle = None
+        if from_idle:
+            time.sleep(0.15)
+            i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            i0.record()
+            step()
+            i1.record()
+            torch.cuda.synchronize()
+            idle = (i0.elapsed_time(i1), sclk_ghz(out["clock"]))
         if args.precondition_ms > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -342,9 +353,9 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0  # this rank's K steps, device work complete; the job's time is the MAX over the ranks (reduce_stats below) --
         barrier()                      # which is what the closing barrier would make every rank read anyway, plus the barrier's own latency
-        return dt, ev0.elapsed_time(ev1) / steps, sclk_ghz(out["clock"]), out
+        return dt, ev0.elapsed_time(ev1) / steps, sclk_ghz(out["clock"]), out, idle
 
-    dt, kern_ms, sclk, out = timed_pass(batch, args.kernel, args.steps, args.warmup)
+    dt, kern_ms, sclk, out, idle = timed_pass(batch, args.kernel, args.steps, args.warmup, from_idle=True)
     fpb, tpb, lds_bytes = opt.kernel_geometry()
 
     # ---- parity on a sample (rank-local), reduced with the timing
@@ -375,7 +386,7 @@ def main():
             lo, hi = shard_bounds(total, world, rank)
             kern = pick_kernel(opt, total, world)
             sb = synth_on_device(opt, total, 1234, device, lo, hi, mixed=s4)
-            sdt, sk, sclk_s, _ = timed_pass(sb, kern, args.steps, args.warmup)
+            sdt, sk, sclk_s, _, _ = timed_pass(sb, kern, args.steps, args.warmup)
             # every rank's own launch time: a one-hot vector summed over the ranks (the same small all-reduce as everything else here)
             (sdt, sk_max), per_rank = reduce_stats(dist, device, max_stats=[sdt, sk], sum_stats=[sk if r == rank else 0.0 for r in range(world)])
             sfpb = opt.kernel_geometry()[0]
@@ -421,6 +432,9 @@ def main():
                          # the roofline's 157.3 TF is the fp32 matrix rate AT 2.4 GHz; the chip holds less than that with every SIMD on the matrix pipe
                          # (profiles/r05_clock_ramp.txt).  frac above stays against the full 157.3; this is the same work against the clock actually held
                          "sclk_ghz": sclk, "frac_at_held_clock": achieved / (PEAK_F32_MFMA * sclk / 2.4) if sclk == sclk and sclk > 0 else None,
+                         # the same launch from an idle GPU (>= 150 ms without work, ONE launch, rank 0's): what a caller who submits one batch gets
+                         "kernel_ms_from_idle": idle[0] if idle else None, "sclk_ghz_from_idle": idle[1] if idle else None,
+                         "frac_from_idle": (Bk * N * FLOP_PER_FRAME_ITER / (idle[0] * 1e-3) / PEAK_F32_MFMA) if idle else None,
                          "kernel": {16: "dp_w4_kernel<4, false>", 64: "dp_w16_kernel<4, 1>", 128: "dp_w16_kernel<8, 2>"}.get(fpb, "?"), "kernel_ms": kern_ms,
                          "frac_of_bf16_mfma_peak_2.5PF": (achieved / 2.5e15 if fpb >= 64 else None),
                          "workgroup": {"frames": fpb, "threads": tpb, "lds_bytes": lds_bytes},

@@ -15,6 +15,7 @@ DP_ERR_INVALID = -1
 DP_ERR_DEVICE = -2
 DP_ERR_UNSUPPORTED = -3
 DP_ERR_LAUNCH = -4
+DP_ERR_TIMEOUT = -5
 DP_WEIGHTS_FP32 = 0
 DP_WEIGHTS_BF16 = 1
 DP_MAX_ITERS = 1000000
@@ -121,6 +122,7 @@ class DpResult(_Sized):
 
 
 DP_STATUS_NONFINITE_RESULT, DP_STATUS_BAD_STATE, DP_STATUS_BAD_TARGETS = 1, 2, 4
+DP_TEMPORAL_TEAM_TIMEOUT = 1
 DP_INPUT_LIMIT = 1.0e4
 
 
@@ -128,7 +130,7 @@ DP_INPUT_LIMIT = 1.0e4
 PUBLIC_SYMBOLS = (
     "dp_version", "dp_last_error", "dp_fold_decoder", "dp_create", "dp_destroy", "dp_optimize",
     "dp_forward", "dp_sequence_advance", "dp_optimize_sequence", "dp_kernel_geometry", "dp_auto_kernel", "dp_io_alloc", "dp_io_free", "dp_io_upload", "dp_io_download", "dp_stream_sync", "dp_io_alloc_host", "dp_io_free_host",
-    "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict",
+    "dp_temporal_create", "dp_temporal_destroy", "dp_temporal_last_error", "dp_temporal_predict", "dp_temporal_status",
 )
 
 _libs = {}
@@ -180,6 +182,8 @@ def load(path=None):
                                       C.c_void_p, C.c_void_p]
     lib.dp_temporal_debug_force_variant.argtypes = [C.c_void_p, C.c_int]
     lib.dp_temporal_debug_team_status.argtypes = [C.c_void_p]
+    lib.dp_temporal_status.argtypes = [C.c_void_p]
+    lib.dp_temporal_debug_team_fault.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.dp_temporal_debug_team_size.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.dp_temporal_debug_split3.argtypes = [C.c_float, C.POINTER(C.c_ushort)]
     lib.dp_temporal_debug_split3.restype = None

@@ -58,8 +58,11 @@ struct TArgs {
     // a TEAM of G workgroups per sequence (few sequences: latency; below): the exchange area of the handle, the tag base of this launch
     float* xch;
     unsigned* epochs; // one word per team: the tag of the team's last exchange (device-resident, so that a captured launch can be replayed)
-    int* tstatus;
+    int* tstatus;     // the handle's status word in DEVICE memory: what every team launch checks at entry and while it waits
+    int* hstatus;     // ... and its mirror in page-locked HOST memory: what dp_temporal_status / the next dp_temporal_predict read without a synchronise
     int G;
+    int poll_limit;   // re-reads of a granule set before a member gives up (XCH_POLL_LIMIT; the debug hook shortens it)
+    int dbg_skip_team, dbg_skip_member; // private test hook: that member of that team never publishes (-1: nobody)
 };
 
 #define DEV __device__ __forceinline__
@@ -405,7 +408,23 @@ DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const 
 // the same counter: never the awaited one.  Nothing of this lives in kernel arguments: a launch captured into a graph can be replayed.
 constexpr int XCH_GRANULES = 2 * 16 * D / 3;          // two token tiles of 16 x 48 partial sums, three per granule
 constexpr int XCH_GMAX = 16;                          // the largest team; slots per granule in the layout
-constexpr int XCH_POLL_LIMIT = 1 << 19;               // (~1 s: then the team gives up, sets the handle's status word and finishes with garbage)
+constexpr int XCH_POLL_LIMIT = 1 << 19;               // (~1 s: then the member gives up -- see "time-out" below)
+// Time-out.  A team waits for its members, so all of them must be resident.  The host sizes teams so that they are (one workgroup per CU by the
+// occupancy query, at most HALF the CUs the stream may use: dp_temporal_predict) -- against its own launch; another stream's long kernel, a CU mask
+// set behind the library's back or a second process can still keep a member off the device.  What happens then is never silent:
+//   * the member that has re-read its granules poll_limit times (~1 s) latches the handle's status word -- in device memory AND in its page-locked
+//     host mirror --, stops waiting for good (`dead`) and, at the end of the block, writes NaN into EVERY target row of its sequence: the optimise
+//     kernel's input screening then reports DP_STATUS_BAD_TARGETS for that sequence (include/dragposer.h) instead of being pulled towards garbage;
+//   * members still waiting see the device word within 256 re-reads and give up the same way; a team launch that finds the word set at entry writes
+//     NaN and leaves at once (a replayed graph, launches already in the queue): nothing of the exchange area is trusted after a time-out -- a late
+//     member may have read the tag counter after it was rewritten and left future-valued tags behind;
+//   * the host reads the mirror without a synchronise: dp_temporal_status(), and the NEXT dp_temporal_predict fails with DP_ERR_TIMEOUT, after
+//     which the handle launches no more teams (one workgroup per sequence from then on).
+// Hardware assumption of the granule (stated, soaked by tests/test_hip_temporal.py::test_team_soak): a 16-byte-aligned global_store_dwordx4 of one
+// lane becomes visible as a whole -- the tag in word 3 never before the three sums.  The ISA's memory model promises single-copy atomicity up to 8
+// bytes only; on gfx950 the 16 bytes travel as one write request inside one 32-byte sector and no tear has ever been observed
+// (profiles/r05_team_soak.txt: 27 k launches; the gated soak test repeats it every GPU run).
+DEV int load_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void store_granule(f4* p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 template <int N> DEV void load_granules(f4 (&v)[16], const f4* p);
 template <> DEV void load_granules<2>(f4 (&v)[16], const f4* p)
@@ -445,9 +464,18 @@ struct Team { // (uniform per workgroup)
     f4* xch;       // this team's exchange area: [2 slots][XCH_GRANULES][XCH_GMAX] granules
     int* status;   // the handle's status word
     unsigned tag;  // tag of the NEXT exchange (counts up: every workgroup of a team makes the same calls in the same order)
+    int* hstatus;  // ... its host mirror
     int g, G;      // this workgroup's rank in its team, the team's size (2, 4, 8 or 16)
-    int* dead;     // (LDS) an exchange of this workgroup has timed out: no further waiting
+    int* dead;     // (LDS) an exchange of this workgroup has timed out (1) / the handle was dead at entry (2): no further waiting
+    int poll_limit;
+    bool mute;     // private test hook: this member never publishes
 };
+DEV void team_timeout(Team* tm)
+{ // latch the handle's status word (device + host mirror), stop waiting for good
+    __hip_atomic_store(tm->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tm->hstatus, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *tm->dead = 1;
+}
 
 // a thread's three outputs: re-read the GG members' granules until all carry the awaited tag, then add them up in member order
 template <int GG> DEV void gather(float (&sum)[3], const f4* src, Team* tm)
@@ -460,7 +488,7 @@ template <int GG> DEV void gather(float (&sum)[3], const f4* src, Team* tm)
 #pragma unroll
         for (int gg = 0; gg < GG; ++gg) all = all && __float_as_uint(v[gg][3]) == tm->tag;
         if (all || dead) break;
-        if (++tries >= XCH_POLL_LIMIT) { *tm->status = 1; *tm->dead = 1; break; } // (gives up: on with what is there, no further waiting)
+        if (++tries >= tm->poll_limit || ((tries & 255) == 0 && load_agent(tm->status) != 0)) { team_timeout(tm); break; } // (gives up: see "time-out" above)
         __builtin_amdgcn_s_sleep(2);
     }
 #pragma unroll
@@ -698,7 +726,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
                         gr[j] = sum;
                     }
                     gr[3] = __uint_as_float(tm->tag);
-                    store_granule(xslot + (size_t)(tt * (16 * D / 3) + i) * XCH_GMAX + tm->g, gr);
+                    if (!tm->mute) store_granule(xslot + (size_t)(tt * (16 * D / 3) + i) * XCH_GMAX + tm->g, gr);
                 }
                 __syncthreads();
                 continue;
@@ -759,8 +787,9 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     if (TEAM) {
         team.g = (int)blockIdx.x - s0 * a.G; team.G = a.G;
         team.xch = (f4*)a.xch + (size_t)s0 * 2 * XCH_GRANULES * XCH_GMAX;
-        team.status = a.tstatus; team.tag = a.epochs[s0] + 1u; team.dead = &team_dead;
-        if (tid == 0) team_dead = 0; // (read after the barriers below)
+        team.status = a.tstatus; team.hstatus = a.hstatus; team.tag = a.epochs[s0] + 1u; team.dead = &team_dead;
+        team.poll_limit = a.poll_limit; team.mute = s0 == a.dbg_skip_team && team.g == a.dbg_skip_member;
+        if (tid == 0) team_dead = load_agent(a.tstatus) != 0 ? 2 : 0; // (read after the barriers below)
     }
     const float* w = a.w;
     STAMP(0);
@@ -805,6 +834,11 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     }
     __syncthreads();
     STAMP(10);
+    if (TEAM && team_dead == 2) { // (uniform) an earlier launch of this handle timed out: the exchange area is not to be trusted -- NaN, at once
+        if (team.g == 0)
+            for (int idx = tid; idx < (a.window + 1) * LAT; idx += NT) a.target[(size_t)s0 * (a.window + 1) * LAT + idx] = __builtin_nanf("");
+        return;
+    }
 
     // ---- encoder, once (the memory is the same for every autoregressive call)
     lin<MAX_IN / 4, NS>(x, D, enc_in, MAX_IN, Te, w + a.ipe_wT, w + a.ipe_b, D, a.n_in, w + a.pe, 16); // (enc_in: 16 rows per sequence)
@@ -861,6 +895,10 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
     // ---- de-normalise, then the reference's "lerp" with weight 1 (drag_pose.py:283-291): frame k of the window holds the
     //      NEXT sampled prediction, the last frame its own
     const int W = a.window;
+    if (TEAM && team_dead != 0) { // (uniform: the last write to it lies behind several barriers) this member gave up waiting: see "time-out"
+        for (int idx = tid; idx < (W + 1) * LAT; idx += NT) a.target[(size_t)s0 * (W + 1) * LAT + idx] = __builtin_nanf("");
+        return;
+    }
     if (TEAM && team.g != 0) return; // (every workgroup of the team holds the result; the first stores it)
     if (TEAM && tid == 0) a.epochs[s0] = team.tag - 1u; // (the team's last tag: every member has read the word long ago -- it has published since)
     for (int idx = tid; idx < NS * (W + 1) * LAT; idx += NT) {
@@ -882,6 +920,10 @@ struct dp_temporal {
     float* d_w = nullptr;
     float* d_xch = nullptr;  // the teams' exchange area: [n_cu / 2 teams][2][XCH_GRANULES][XCH_GMAX] granules, the teams' tag counters, the status word
     size_t xch_granule_bytes = 0;
+    int* h_status = nullptr; // page-locked host mirror of the status word (written by the device on a team time-out, read here without a synchronise)
+    int status_seen = 0;     // DP_TEMPORAL_* bits ever seen in it (sticky)
+    bool teams_off = false;  // no team launches any more: a time-out was reported, or the TEAM kernel does not fit a CU of this device
+    int poll_limit = XCH_POLL_LIMIT, dbg_skip_team = -1, dbg_skip_member = -1; // dp_temporal_debug_team_fault (private test hook)
     TArgs args{};
     std::string err;
 };
@@ -1076,10 +1118,18 @@ extern "C" int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m,
     const size_t xch_bytes = t->xch_granule_bytes + (size_t)max_teams * sizeof(unsigned) + 16;
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_xch, xch_bytes);
     if (e == hipSuccess) e = hipMemset(t->d_xch, 0, xch_bytes); // (tag 0 = never written; a team's first exchange carries tag 1)
+    if (e == hipSuccess) e = hipHostMalloc((void**)&t->h_status, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        *t->h_status = 0;
+        // a team member needs a CU's worth of LDS and registers: co-residency is sized from what the RUNTIME says fits, not from this file's arithmetic
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_temporal_kernel<2, 1, true>, NT, 0) != hipSuccess || per_cu < 1) t->teams_off = true;
+    }
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         if (t->d_w) (void)hipFree(t->d_w);
         if (t->d_xch) (void)hipFree(t->d_xch);
+        if (t->h_status) (void)hipHostFree(t->h_status);
         delete t;
         return tfail(nullptr, DP_ERR_DEVICE, std::string("dp_temporal_create: ") + hipGetErrorString(e));
     }
@@ -1097,6 +1147,7 @@ extern "C" int dp_temporal_destroy(dp_temporal* t)
     (void)hipSetDevice(t->device);
     if (t->d_w) (void)hipFree(t->d_w);
     if (t->d_xch) (void)hipFree(t->d_xch);
+    if (t->h_status) (void)hipHostFree(t->h_status);
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
     delete t;
     return DP_OK;
@@ -1125,17 +1176,38 @@ extern "C" int dp_temporal_debug_force_variant(dp_temporal* t, int variant)
     return DP_OK;
 }
 
-// The team size the library picks for n_seq sequences on a device of n_cu CUs (1: no teams).  Host arithmetic only (a CPU test holds it): the
+// The team size the library picks for n_seq sequences on a device of n_cu usable CUs (1: no teams).  Host arithmetic only (a CPU test holds it): the
 // largest power of two up to 16 with every workgroup on a CU of its own (team members wait for each other: all of them must be resident, and the
-// TEAM kernel's 86 KB of LDS allow one workgroup per CU) and at least one feed-forward tile per wave; 16 pays with a quarter of the device at most
-// (profiles/r05_team_latency.txt), 8 beyond.
+// TEAM kernel's 86 KB of LDS allow one workgroup per CU), ALL TEAMS TOGETHER ON AT MOST HALF THE CUs (round 6: the other half is what keeps a second
+// handle's teams, or another stream's kernel, from starving a member -- a launch that filled the device left no slack at all) and at least one
+// feed-forward tile per wave; 16 pays with a quarter of the device at most (profiles/r05_team_latency.txt), 8 beyond.
 extern "C" int dp_temporal_debug_team_size(int n_cu, int n_seq, int dim_feedforward)
 {
     if (n_cu <= 0 || n_seq <= 0 || dim_feedforward <= 0) return 1;
     int G = 1;
-    while (G < 16 && n_seq * (2 * G) <= n_cu && (dim_feedforward + FT - 1) / FT >= 2 * G * NWV) G *= 2;
+    while (G < 16 && n_seq * (2 * G) <= n_cu / 2 && (dim_feedforward + FT - 1) / FT >= 2 * G * NWV) G *= 2;
     if (G == 16 && n_seq * 64 > n_cu) G = 8;
     return G;
+}
+
+// private test hook: make the team exchange fail on purpose -- member `member` of sequence `team`'s team never publishes its partial sums (-1: nobody),
+// and a member gives up after `poll_limit` re-reads instead of ~1 s (0: the default).  What the product promises then is in "time-out" above.
+extern "C" int dp_temporal_debug_team_fault(dp_temporal* t, int team, int member, int poll_limit)
+{
+    if (!t) return DP_ERR_INVALID;
+    t->dbg_skip_team = team; t->dbg_skip_member = member;
+    t->poll_limit = poll_limit > 0 ? poll_limit : XCH_POLL_LIMIT;
+    return DP_OK;
+}
+
+// Health of the handle, WITHOUT a synchronise: DP_TEMPORAL_TEAM_TIMEOUT once a team member of an earlier launch has given up waiting (the device
+// writes the word into page-locked host memory the moment it happens; sticky).  The targets of that launch's affected sequences are NaN.
+extern "C" int dp_temporal_status(const dp_temporal* t)
+{
+    if (!t) return DP_ERR_INVALID;
+    int v = t->status_seen;
+    if (t->h_status && *(volatile const int*)t->h_status != 0) v |= DP_TEMPORAL_TEAM_TIMEOUT;
+    return v;
 }
 
 // private test hook: the teams' status word (0: every exchange completed; 1: a workgroup waited XCH_POLL_LIMIT reads for its team -- the launch's
@@ -1160,6 +1232,13 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     const int n_past = (st->history + m.step - 1) / m.step, n_steps = window / m.step + 1;
     if (st->history < 2 * m.step || n_past - 1 > MAXT || n_steps > MAXT || n_past - 1 > m.max_len || n_steps > m.max_len)
         return tfail(t, DP_ERR_UNSUPPORTED, "dp_temporal_predict: more than 32 encoder or decoder tokens (or more than max_len positions)");
+    if (!t->teams_off && *(volatile const int*)t->h_status != 0) { // a team member of an EARLIER launch gave up waiting (see "time-out")
+        t->teams_off = true;
+        t->status_seen |= DP_TEMPORAL_TEAM_TIMEOUT;
+        return tfail(t, DP_ERR_TIMEOUT, "dp_temporal_predict: a team of workgroups of an earlier launch of this handle timed out waiting for a member that was not "
+                                        "resident (another stream's kernel or a CU mask held its CUs?); that launch wrote NaN into the targets of the affected "
+                                        "sequences.  Nothing was launched now; the handle runs one workgroup per sequence from here on -- call again");
+    }
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != t->device && hipSetDevice(t->device) != hipSuccess) return tfail(t, DP_ERR_DEVICE, "cannot select the predictor's device");
@@ -1172,17 +1251,29 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? 42 : 41);
     // few sequences: a TEAM of G workgroups per sequence (the largest power of two up to 16 with every workgroup on a CU of its own -- they wait for
     // each other, so all of them must be resident -- and at least one feed-forward tile per wave)
-    int G = dp_temporal_debug_team_size(t->n_cu, n_seq, m.ff);
-    if (t->forced_variant >= 100) { // (a forced size: the largest the launch fits, whatever pays)
-        G = 1;
-        while (G < 16 && n_seq * (2 * G) <= t->n_cu && (m.ff + FT - 1) / FT >= 2 * G * NWV) G *= 2;
+    // (the CUs this launch may use: the device's, or the stream's CU mask when it has one -- hipExtStreamGetCUMask reports the effective mask)
+    int n_cu = t->n_cu;
+    {
+        uint32_t mask[16] = {};
+        if (hipExtStreamGetCUMask((hipStream_t)stream, 16, mask) == hipSuccess) {
+            int bits = 0;
+            for (uint32_t w : mask) bits += __builtin_popcount(w);
+            if (bits > 0 && bits < n_cu) n_cu = bits;
+        } else (void)hipGetLastError(); // (not an error of this call)
     }
-    if (t->forced_variant >= 100) { const int want = t->forced_variant - 100; G = G >= want ? want : 1; }
+    int G = t->teams_off ? 1 : dp_temporal_debug_team_size(n_cu, n_seq, m.ff);
+    if (t->forced_variant >= 100 && !t->teams_off) { // (a forced size: the largest the launch fits -- here the whole device may be used --, whatever pays)
+        G = 1;
+        while (G < 16 && n_seq * (2 * G) <= n_cu && (m.ff + FT - 1) / FT >= 2 * G * NWV) G *= 2;
+        const int want = t->forced_variant - 100;
+        G = G >= want ? want : 1;
+    }
     if (G >= 2 && (t->forced_variant == 0 || t->forced_variant >= 100)) variant = 100 + G;
     if (t->forced_variant == 21 || t->forced_variant == 41 || (t->forced_variant == 42 && pair_ok)) variant = t->forced_variant;
     if (variant >= 100) {
         const int max_teams = t->n_cu / 2 > 0 ? t->n_cu / 2 : 1;
         a.G = G; a.xch = t->d_xch; a.epochs = (unsigned*)((char*)t->d_xch + t->xch_granule_bytes); a.tstatus = (int*)(a.epochs + max_teams);
+        a.hstatus = t->h_status; a.poll_limit = t->poll_limit; a.dbg_skip_team = t->dbg_skip_team; a.dbg_skip_member = t->dbg_skip_member;
         hipLaunchKernelGGL((dp_temporal_kernel<2, 1, true>), dim3(n_seq * G), dim3(NT), 0, (hipStream_t)stream, a);
     } else if (variant == 21) hipLaunchKernelGGL((dp_temporal_kernel<2, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
     else if (variant == 41) hipLaunchKernelGGL((dp_temporal_kernel<4, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);

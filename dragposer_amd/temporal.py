@@ -138,6 +138,17 @@ class NativeTemporal:
         if rc != 0:
             raise ValueError(f"dp_temporal_debug_force_variant({variant}) -> {rc}")
 
+    def status(self):
+        """DP_TEMPORAL_* bits of the handle, read without synchronising (include/dragposer.h: dp_temporal_status): 1 once a team of workgroups of
+        an earlier launch gave up waiting for a member -- that launch's targets are NaN for the affected sequences, and the next predict() raises"""
+        return int(self._lib.dp_temporal_status(self._h))
+
+    def _team_fault(self, team=-1, member=-1, poll_limit=0):
+        """tests only: member `member` of sequence `team`'s team never publishes its partial sums; a member gives up after poll_limit re-reads"""
+        rc = self._lib.dp_temporal_debug_team_fault(self._h, int(team), int(member), int(poll_limit))
+        if rc != 0:
+            raise ValueError(f"dp_temporal_debug_team_fault -> {rc}")
+
     def _team_status(self):
         """tests only (synchronises): 0 = every exchange between the workgroups of a team has completed"""
         return int(self._lib.dp_temporal_debug_team_status(self._h))

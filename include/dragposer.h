@@ -63,7 +63,9 @@ typedef enum dp_status {
     DP_ERR_INVALID = -1,     /* NULL pointer, bad size, unsupported topology */
     DP_ERR_DEVICE = -2,      /* no gfx950 device / HIP runtime failure */
     DP_ERR_UNSUPPORTED = -3, /* valid request this build does not implement */
-    DP_ERR_LAUNCH = -4       /* kernel launch failed */
+    DP_ERR_LAUNCH = -4,      /* kernel launch failed */
+    DP_ERR_TIMEOUT = -5      /* dp_temporal_predict (0.5.1): a team of workgroups of an EARLIER launch of the handle gave up waiting for a member;
+                                see dp_temporal_status */
 } dp_status;
 
 typedef enum dp_weight_dtype {
@@ -328,6 +330,17 @@ const char* dp_temporal_last_error(const dp_temporal* t); /* NULL: last failure 
  * sequences as the device has CUs, the workgroups that share a sequence exchange partial sums through memory the handle owns.  Such a launch
  * may be captured into a graph and replayed (the exchange keeps its counters on the device). */
 int dp_temporal_predict(dp_temporal* t, int n_sequences, const dp_seq_state* state, int window, float* target_buf, void* hip_stream);
+/* Health of a handle, read WITHOUT synchronising anything (0.5.1).  Launches of few sequences run TEAMS of workgroups per sequence whose members
+ * wait for each other's partial sums, so every member must be resident on a CU.  The library sizes teams for that -- one workgroup per CU by the
+ * runtime's occupancy query, all teams of a launch on at most half of the CUs the stream may use -- but cannot see what else the device is
+ * running (another stream's long kernel, a second process, a CU mask set later).  If a member still waits after ~1 s it GIVES UP, and that is never
+ * silent: (1) every target row of its sequence is NaN -- dp_optimize / dp_optimize_sequence then report DP_STATUS_BAD_TARGETS for the sequence
+ * instead of pulling it towards garbage; (2) this word carries DP_TEMPORAL_TEAM_TIMEOUT from that moment on (the device writes it into page-locked
+ * host memory; sticky); (3) team launches of the handle already queued or replayed from a graph write NaN and leave at once; (4) the NEXT
+ * dp_temporal_predict launches nothing and returns DP_ERR_TIMEOUT (message: dp_temporal_last_error) -- from then on the handle runs one workgroup
+ * per sequence, so calling again works. */
+#define DP_TEMPORAL_TEAM_TIMEOUT 1
+int dp_temporal_status(const dp_temporal* t); /* >= 0: DP_TEMPORAL_* bits; DP_ERR_INVALID for NULL */
 
 /* Device-buffer helpers for callers that have no HIP binding of their own (the native Unity drop-in,
  * include/dragposer_unity.h).  Thin wrappers over hipMalloc / hipFree / hipMemcpyAsync / hipStreamSynchronize on the

@@ -185,6 +185,7 @@ int dp_temporal_create(dp_temporal** out, const dp_temporal_model* m, int d) { (
 int dp_temporal_destroy(dp_temporal* t) { (void)t; return DP_ERR_UNSUPPORTED; }
 const char* dp_temporal_last_error(const dp_temporal* t) { (void)t; return g_create_err; }
 int dp_temporal_predict(dp_temporal* t, int n, const dp_seq_state* s, int w, float* b, void* q) { (void)t; (void)n; (void)s; (void)w; (void)b; (void)q; return DP_ERR_UNSUPPORTED; }
+int dp_temporal_status(const dp_temporal* t) { (void)t; return DP_ERR_UNSUPPORTED; }
 int dp_io_alloc(dp_ctx* c, unsigned long long n, void** p) { if (!c || !p) return DP_ERR_INVALID; *p = malloc(n); return *p ? DP_OK : DP_ERR_DEVICE; }
 int dp_io_free(dp_ctx* c, void* p) { if (!c) return DP_ERR_INVALID; free(p); return DP_OK; }
 int dp_io_upload(dp_ctx* c, void* d, const void* s, unsigned long long n, void* q) { (void)q; if (!c || !d || !s) return DP_ERR_INVALID; memcpy(d, s, n); return DP_OK; }

@@ -172,3 +172,130 @@ def test_predictor_rejects_what_it_cannot_run():
         nat.predict(z(1, 60, 24), z(1, 60, 3), z(1, 60, 6), 200)  # more target positions than pos_encoding has rows
     out = nat.predict(z(2, 60, 24), z(2, 60, 3), z(2, 60, 6), 8)
     assert torch.isfinite(out).all()
+
+
+def _full_size_predictor(seed):
+    from dragposer_amd.temporal import TemporalPredictor
+
+    torch.manual_seed(seed)
+    model = TemporalPredictor().eval()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    return model
+
+
+def _history(S, seed, H=60):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(S, H, 24, generator=g).cuda(), (0.02 * torch.randn(S, H, 3, generator=g)).cuda(), (1.0 + 0.3 * torch.randn(S, H, 6, generator=g)).cuda())
+
+
+def test_a_team_time_out_is_never_silent():
+    """include/dragposer.h, dp_temporal_status: a team member that never publishes (private fault hook; in the field: a member that is not resident)
+    makes its team give up -- the sequence's targets are NaN (so that dp_optimize reports DP_STATUS_BAD_TARGETS instead of being pulled towards
+    garbage), every OTHER sequence is bit-identical to the clean launch, the status word is readable without a synchronise, a team launch already
+    captured in a graph writes NaN at once when replayed, the NEXT predict fails with DP_ERR_TIMEOUT, and the one after that works again (one
+    workgroup per sequence)."""
+    from dragposer_amd import _lib
+    from dragposer_amd.optimizer import LatentOptimizer, to_device_batch
+    from dragposer_amd.temporal import NativeTemporal
+
+    model = _full_size_predictor(6)
+    nat = NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+    nat._force_variant(108)
+    S, window = 3, 16
+    lat, disp, hts = _history(S, 31)
+    clean = nat.predict(lat, disp, hts, window).clone()
+    torch.cuda.synchronize()
+    assert nat.status() == 0 and nat._team_status() == 0 and torch.isfinite(clean).all()
+    out_g = torch.empty_like(clean)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        nat.predict(lat, disp, hts, window, out=out_g)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, clean)
+
+    nat._team_fault(team=1, member=2, poll_limit=4096)  # (a member gives up after 4096 re-reads, not after a second)
+    got = nat.predict(lat, disp, hts, window)
+    torch.cuda.synchronize()
+    assert torch.isnan(got[1]).all(), "the affected sequence's targets are NaN, every row"
+    assert torch.equal(got[0], clean[0]) and torch.equal(got[2], clean[2]), "the other teams never noticed"
+    assert nat.status() == _lib.DP_TEMPORAL_TEAM_TIMEOUT  # (page-locked host word: no synchronise inside)
+    # what the optimise kernel makes of such a target: the frame is refused, with the reason
+    model_o = R.OracleModel()
+    batch = R.synth_inputs(model_o, 4, trackers=6)
+    batch["z_tgt"][1] = got[1, 0].cpu().numpy()
+    opt = LatentOptimizer(device="cuda:0")
+    res = opt.optimize(**to_device_batch(batch, opt.device), n_iter=5, lambda_tmp=0.02, outputs=("z", "status"))
+    st = res["status"].cpu().numpy()
+    assert st[1] & _lib.DP_STATUS_BAD_TARGETS and not (st[[0, 2, 3]] & _lib.DP_STATUS_BAD_TARGETS).any()
+    # a team launch that is already in a graph: the handle is dead on the device, so it writes NaN and leaves (no second's wait per exchange)
+    nat._team_fault(-1, -1, 0)
+    import time
+
+    t0 = time.perf_counter()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5 and torch.isnan(out_g).all()
+    # the next call says so and launches nothing; the one after runs without teams
+    with pytest.raises(_lib.DragPoserError) as e:
+        nat.predict(lat, disp, hts, window)
+    assert e.value.code == _lib.DP_ERR_TIMEOUT and "timed out" in str(e.value)
+    nat._force_variant(0)
+    again = nat.predict(lat, disp, hts, window)
+    torch.cuda.synchronize()
+    assert (again - clean).abs().max().item() <= 1e-6 and nat.status() == _lib.DP_TEMPORAL_TEAM_TIMEOUT  # (sticky)
+
+
+def test_two_handles_run_teams_on_two_streams_at_once():
+    """Two handles have two exchange areas, and the library keeps the teams of ONE launch on at most half of the CUs: two team launches in flight
+    together (two streams) are both resident, neither waits for the other, both give what they give alone."""
+    from dragposer_amd.temporal import NativeTemporal
+
+    model = _full_size_predictor(7)
+    a = NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+    b = NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+    S, window = 16, 16  # (the library's own choice for 16 sequences: teams of 8 = 128 workgroups = half the device, each)
+    ha, hb = _history(S, 41), _history(S, 42)
+    want_a, want_b = a.predict(*ha, window).clone(), b.predict(*hb, window).clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(20):
+        with torch.cuda.stream(sa):
+            ga = a.predict(*ha, window)
+        with torch.cuda.stream(sb):
+            gb = b.predict(*hb, window)
+        torch.cuda.synchronize()
+        assert torch.equal(ga, want_a) and torch.equal(gb, want_b)
+    assert a.status() == 0 and b.status() == 0 and a._team_status() == 0 and b._team_status() == 0
+
+
+def test_team_soak():
+    """The granule exchange rests on one hardware assumption (dp_temporal.hip, "time-out"): a lane's 16-byte store becomes visible as a whole.  A
+    torn granule would be a silently wrong sum, so every GPU run soaks it: a few thousand team launches of random sequence counts, windows and inputs
+    over ONE exchange area (every team size in turn), each equal to its own repeats bit for bit and to the one-workgroup kernel within 1e-5."""
+    import time
+
+    from dragposer_amd.temporal import NativeTemporal
+
+    model = _full_size_predictor(8)
+    team = NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+    solo = NativeTemporal(model, torch.zeros(24), torch.ones(24), device="cuda:0")
+    solo._force_variant(21)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    t0, n, worst = time.time(), 0, 0.0
+    while time.time() - t0 < 12.0:
+        S = int(torch.randint(1, 65, (1,), generator=g))
+        window = 4 * int(torch.randint(0, 16, (1,), generator=g))
+        lat, disp, hts = torch.randn(S, 60, 24, generator=g).cuda(), (0.02 * torch.randn(S, 60, 3, generator=g)).cuda(), (1.0 + 0.3 * torch.randn(S, 60, 6, generator=g)).cuda()
+        reps = int(torch.randint(1, 6, (1,), generator=g))
+        outs = [team.predict(lat, disp, hts, window) for _ in range(reps)]
+        want = solo.predict(lat, disp, hts, window)
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (S, window)
+        worst = max(worst, float((outs[0] - want).abs().max()))
+        n += reps
+    assert worst <= 1e-5 and team.status() == 0 and team._team_status() == 0
+    print(f"team soak: {n} launches in {time.time() - t0:.0f} s, max |team - one workgroup per sequence| = {worst:.2e}")
