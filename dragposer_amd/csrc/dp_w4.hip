@@ -189,6 +189,34 @@ DEV f4 add_halves(f4 v)
     }
     return v;
 }
+// ---- Adam's state in HALF the registers (round 6; the fixed-count kernel).  The latent lives in layout D -- lane = latent dim (24 of 64 lanes),
+// register = frame -- so z, m, v, z_tgt and the gradient are four registers each of which 40 lanes idle, and every step of the update (13 packed
+// instructions and eight 16-cycle sqrt / rcp) is issued twice.  bL0 leaves the gradient as two half sums in lanes l and l ^ 32 (above): instead of
+// giving BOTH halves the sum of all four frames (add_halves: four swaps), one v_permlane32_swap per frame PAIR gives lanes 0..31 the sums of frames
+// 0 | 1 and lanes 32..63 those of frames 2 | 3 -- "packed": register p, lane l = frame p + 2 (l >> 5), dim l & 31.  The whole update runs on two
+// registers per quantity (half the instructions, same arithmetic per element: outputs bit-identical), and the new latent goes back to layout D for
+// the next L0 with two swaps.
+DEV f2 pack_frames(const f4& v)
+{ // lanes 0..31 keep frames 0 | 1 of their dim, lanes 32..63 take frames 2 | 3 of dim l - 32
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+    return f2{__uint_as_float(a[0]), __uint_as_float(b[0])};
+}
+DEV f4 unpack_frames(const f2& p)
+{ // layout D again, valid in lanes 0..31 (the upper half holds copies: finite, never read -- the products take K-rows 0..23)
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(p[0]), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(p[1]), false, false);
+    return f4{__uint_as_float(a[0]), __uint_as_float(b[0]), __uint_as_float(a[1]), __uint_as_float(b[1])};
+}
+DEV f2 add_halves_packed(const f4& v)
+{ // the two half sums of bL0 joined per frame pair: lanes 0..31 = frames 0 | 1, lanes 32..63 = frames 2 | 3 (lo + hi, as add_halves adds them)
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+    return f2{__uint_as_float(a[0]), __uint_as_float(b[0])} + f2{__uint_as_float(a[1]), __uint_as_float(b[1])};
+}
+#ifndef W4_PACKED_ADAM
+#define W4_PACKED_ADAM 1
+#endif
 template <int NG, int ABID0 = 0, unsigned SKIP = 0u> DEV void load_w(f4* wv, const f4* w)
 { // (SKIP as in chain_a / chain_v: the weights of a group that is left out are not read)
     static_for<NG>([&](auto gi) {
@@ -1077,6 +1105,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 #define SQ_STAMP(i)
 #endif
     double* adx = (double*)(lds + lds_adx<NW>()) + 2 * wave;
+    // packed Adam state (pack_frames above): the fixed-count kernel only -- the while-condition's per-frame selects act on whole registers
+    constexpr bool PK = W4_PACKED_ADAM && !EARLY;
+    f2 zP = {0.f, 0.f}, ztP = zP, mP = zP, vP = zP;
+    f4 xz = zD; // the latent in layout D for the next L0
+    const int lane5 = lane & 31, fhalf = lane >> 5; // packed: my dim, my frame pair (frames fhalf * 2 + register ... see pack_frames: frame p + 2 fhalf)
+    if constexpr (PK) { zP = pack_frames(zD); ztP = pack_frames(ztD); }
     do { // (one pass unless SEQ)
     if (LONG) { adx[0] = a.cont.b1t; adx[1] = a.cont.b2t; } // (every frame / step starts Adam afresh, drag_pose.py:218)
     if (SEQ) {
@@ -1153,7 +1187,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         const f4* w2 = (const f4*)(lds + L_IMG2) + o;
 
         // ================= L0: a0 = lrelu(A0 z + c0)
-        f4 x = zD;
+        f4 x = PK ? xz : zD;
         QT(x);
         f4 acc0, acc1;
         chain_a<6, 0, 1>(acc0, acc1, x, wL0, bias0T);
@@ -1312,9 +1346,19 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         chain3_v_zero<5>(acc0, acc1, x, wz); // two K-steps per instruction: lanes 0..31 | 32..63 hold the two halves of the sum
         chain_end(acc0, acc1);
         __builtin_amdgcn_sched_barrier(0); // (keeps the subtraction below out of the chains above: w4_probe, "independent v_pk_fma")
-        const f4 g = add_halves(acc0 + acc1) + a.ctmp * (zD - ztD);
+        f4 g = {0.f, 0.f, 0.f, 0.f};
+        f2 gP = {0.f, 0.f};
+        if constexpr (PK) gP = add_halves_packed(acc0 + acc1) + a.ctmp * (zP - ztP);
+        else g = add_halves(acc0 + acc1) + a.ctmp * (zD - ztD);
         STAMP(8);
-        if (DBG_DUMP && a.dbg && iter == 0 && lane < LAT) {
+        if (PK && DBG_DUMP && a.dbg && iter == 0 && lane5 < LAT) {
+            int ld = lane5;
+            asm volatile("" : "+v"(ld));
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (f0 + r + 2 * fhalf < nB) a.dbg[(size_t)(f0 + r + 2 * fhalf) * DBG_STRIDE + DBG_GZ + ld] = gP[r];
+        }
+        if (!PK && DBG_DUMP && a.dbg && iter == 0 && lane < LAT) {
             int ld = lane;
             asm volatile("" : "+v"(ld)); // (opaque: the four 64-bit addresses of this once-per-launch dump are not to be formed ahead of the loop and held across it)
 #pragma unroll
@@ -1322,9 +1366,20 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                 if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + ld] = g[r];
         }
 #ifdef W4_ABLATE_ADAM
-        zD = zD - 1e-6f * g;
+        if constexpr (PK) { zP = zP - 1e-6f * gP; xz = unpack_frames(zP); }
+        else zD = zD - 1e-6f * g;
 #else
-        if (!EARLY) {
+        if constexpr (PK) {
+            if (last && lane5 < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
+#pragma unroll
+                for (int r = 0; r < 2; ++r) fb0[(r + 2 * fhalf) * FB_STRIDE + FB_ZPRE + lane5] = zP[r];
+            }
+            mP = mP + a.one_m_b1 * (gP - mP);
+            vP = vP * a.beta2 + a.one_m_b2 * (gP * gP);
+            const f2 den = f2{__builtin_amdgcn_sqrtf(vP.x), __builtin_amdgcn_sqrtf(vP.y)} * rbc2s + a.eps;
+            zP = zP - step * (mP * f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
+            xz = unpack_frames(zP);
+        } else if (!EARLY) {
             if (last && lane < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
 #pragma unroll
                 for (int r = 0; r < FPW; ++r) fb0[r * FB_STRIDE + FB_ZPRE + lane] = zD[r];
@@ -1369,6 +1424,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.t[17] = __builtin_amdgcn_s_memtime() - mt0;     // shader cycles over the loop
 #endif
     SQ_STAMP(1);
+    if constexpr (PK) { if (optimise) zD = xz; } // (layout D again: what the epilogue stores; a forward-only launch never left it)
     // ================= epilogue: outputs of the LAST forward pass (decoder quads still in registers; unit quaternions,
     // bones and the tracker loss terms in the frame blocks)
     const auto& ae = step_args_of<SEQ>(a, lds);
