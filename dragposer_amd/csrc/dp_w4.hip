@@ -202,11 +202,13 @@ DEV f2 pack_frames(const f4& v)
     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
     return f2{__uint_as_float(a[0]), __uint_as_float(b[0])};
 }
-DEV f4 unpack_frames(const f2& p)
-{ // layout D again, valid in lanes 0..31 (the upper half holds copies: finite, never read -- the products take K-rows 0..23)
-    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(p[0]), false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(p[1]), false, false);
-    return f4{__uint_as_float(a[0]), __uint_as_float(b[0]), __uint_as_float(a[1]), __uint_as_float(b[1])};
+DEV f4 unpack_frames(const f2& p, const f4& old)
+{ // layout D again, valid in lanes 0..31 -- all a product reads (K-rows 0..23); the upper halves hold finite leftovers.  Frames 0 | 1 ARE the packed
+  // registers' lower halves; frames 2 | 3 come down with one swap each, into the registers of the previous iteration's copy (`old`: dead, finite)
+  // -- the swap's other operand is a throw-away copy of the packed register, so it costs one move, not two
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(old[2]), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(old[3]), false, false);
+    return f4{p[0], p[1], __uint_as_float(a[1]), __uint_as_float(b[1])};
 }
 DEV f2 add_halves_packed(const f4& v)
 { // the two half sums of bL0 joined per frame pair: lanes 0..31 = frames 0 | 1, lanes 32..63 = frames 2 | 3 (lo + hi, as add_halves adds them)
@@ -1087,10 +1089,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     prof.start();
 #ifdef DP_PROFILE
     prof.t[10] = prof.prev - t_entry; // kernel entry -> first iteration
+#ifndef W4_STAMP_L0 // (-DW4_STAMP_L0: slots 12..15 take the sub-phases of L0 instead -- Adam's tail | D -> X transpose | 24 K-steps | LeakyReLU; slot 0 is then empty)
     prof.t[12] = t_setup[0] - t_entry;    // image fetched into LDS (barrier), flags decoded, tracker loads issued
     prof.t[13] = t_setup[1] - t_setup[0]; // registers filled from LDS (barrier), frame blocks, trackers
     prof.t[14] = t_setup[2] - t_setup[1]; // LDS image, barrier
     prof.t[15] = prof.prev - t_setup[2];  // resident weights arrived
+#endif
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), mt0 = prof.prev;
 #endif
     // dp_result.clock: shader cycles and 100 MHz ticks workgroup 0 spends from here to its last store (four scalar instructions per launch)
@@ -1188,12 +1192,31 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
 
         // ================= L0: a0 = lrelu(A0 z + c0)
         f4 x = PK ? xz : zD;
+#ifdef W4_STAMP_L0
+        { // (a scalar read of the new latent: the stamp below cannot be taken before the Adam step's last result EXISTS -- what was still in flight is slot 12's)
+            int t_;
+            asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 3\n\ts_add_u32 %0, %0, 0" : "=s"(t_) : "v"(x[2]) : "scc");
+        }
+        STAMP(12);
+#endif
         QT(x);
+#ifdef W4_STAMP_L0
+        { int t_; asm volatile("s_nop 3\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 3\n\ts_add_u32 %0, %0, 0" : "=s"(t_) : "v"(x[3]) : "scc"); }
+        STAMP(13);
+#endif
         f4 acc0, acc1;
         chain_a<6, 0, 1>(acc0, acc1, x, wL0, bias0T);
         chain_end(acc0, acc1);
+#ifdef W4_STAMP_L0
+        STAMP(14);
+#endif
         const f4 f0D = lrelu_factor(acc0 + acc1); // kept for the backward
+#ifdef W4_STAMP_L0
+        { int t_; asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 3\n\ts_add_u32 %0, %0, 0" : "=s"(t_) : "v"(f0D[3]) : "scc"); }
+        STAMP(15);
+#else
         STAMP(0);
+#endif
         // ================= L1: a1 = lrelu(A1 a0 + b1)
         x = (acc0 + acc1) * f0D;
         QT(x);
@@ -1366,7 +1389,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                 if (f0 + r < nB) a.dbg[(size_t)(f0 + r) * DBG_STRIDE + DBG_GZ + ld] = g[r];
         }
 #ifdef W4_ABLATE_ADAM
-        if constexpr (PK) { zP = zP - 1e-6f * gP; xz = unpack_frames(zP); }
+        if constexpr (PK) { zP = zP - 1e-6f * gP; xz = unpack_frames(zP, xz); }
         else zD = zD - 1e-6f * g;
 #else
         if constexpr (PK) {
@@ -1378,7 +1401,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             vP = vP * a.beta2 + a.one_m_b2 * (gP * gP);
             const f2 den = f2{__builtin_amdgcn_sqrtf(vP.x), __builtin_amdgcn_sqrtf(vP.y)} * rbc2s + a.eps;
             zP = zP - step * (mP * f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
-            xz = unpack_frames(zP);
+            xz = unpack_frames(zP, xz);
         } else if (!EARLY) {
             if (last && lane < LAT) { // (uniform) latent of this, the last, forward pass: for the epilogue
 #pragma unroll
@@ -1411,6 +1434,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
                 }
             }
         }
+#endif
+#ifdef W4_STAMP_L0
+        { int t_; asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 3\n\ts_add_u32 %0, %0, 0" : "=s"(t_) : "v"(PK ? xz[3] : zD[3]) : "scc"); } // (Adam's slot ends when its result exists)
 #endif
         STAMP(9);
 #ifdef DP_PROFILE

@@ -5,7 +5,7 @@ set -e
 mkdir -p gpurun_out
 FLAGS=$(python3 -c "import __graft_entry__ as g; print(' '.join(g.HIPCC_FLAGS))")
 SRCS=$(python3 -c "import __graft_entry__ as g; print(' '.join(g.HIP_SOURCES))")
-( cd dragposer_amd/csrc && hipcc $FLAGS -DDP_PROFILE -DDP_PROFILE_WAVE=${PWAVE:-0} -o ../../gpurun_out/libdp_prof.so $SRCS )
+( cd dragposer_amd/csrc && hipcc $FLAGS -DDP_PROFILE ${EXTRA_DEFS} -DDP_PROFILE_WAVE=${PWAVE:-0} -o ../../gpurun_out/libdp_prof.so $SRCS )
 ( cd dragposer_amd/csrc && hipcc $FLAGS -DDP_PROFILE -DDP_PROFILE_WAVE=${PWAVE:-0} -DDP_REF8_BUILD -o ../../gpurun_out/libdp_prof8.so $SRCS dp_kernel.hip )
 for spec in ${SPECS:-"4096:0:w4"}; do
   IFS=: read frames hint kern <<< "$spec"

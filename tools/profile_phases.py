@@ -38,6 +38,10 @@ grid = (B + fpb - 1) // fpb
 print(f"kernel: {fpb} frames / {tpb} threads per workgroup, {grid} workgroups")
 raw = dbg.cpu().numpy()[: grid * 40].view(np.uint64).reshape(grid, 20).astype(np.float64) / N
 p = raw[:, :len(NAMES)]
+L0SUB = os.environ.get("PHASE_L0") == "1"  # build with EXTRA_DEFS=-DW4_STAMP_L0: slots 12..15 = the sub-phases of L0, slot 0 empty
+if L0SUB:
+    p = np.concatenate([p, raw[:, 12:16]], axis=1)
+    NAMES = list(NAMES) + ["  L0: Adam's tail (new latent arrives)", "  L0: D -> X transpose", "  L0: 24 K-steps + chain end", "  L0: LeakyReLU factor"]
 tot = p.sum(1)
 print(f"B={B}: cycles/iteration (s_memtime ticks) mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(NAMES):
@@ -46,7 +50,8 @@ if os.environ.get("PHASE_KERNEL", "w4") == "w4":
     print(f"  per launch: entry -> first iteration {raw[:, 10].mean() * N:.0f} cycles, last iteration -> stores done {raw[:, 11].mean() * N:.0f} cycles "
           f"(max over workgroups {raw[:, 10].max() * N:.0f} / {raw[:, 11].max() * N:.0f})")
     print(f"  shader clock held over the loop: {raw[:, 17].mean() / raw[:, 16].mean() * 0.1:.3f} GHz (s_memtime / s_memrealtime)")
-    print("  setup split (time of arrival, no drain): image into LDS + flags + tracker loads issued {:.0f}, registers from LDS + frame blocks + trackers {:.0f}, barrier {:.0f}, loop entry {:.0f}".format(
+    if not L0SUB:
+      print("  setup split (time of arrival, no drain): image into LDS + flags + tracker loads issued {:.0f}, registers from LDS + frame blocks + trackers {:.0f}, barrier {:.0f}, loop entry {:.0f}".format(
         *[raw[:, i].mean() * N for i in (12, 13, 14, 15)]))
     print(f"  first iteration {raw[:, 18].mean() * N:.0f} cycles, second {raw[:, 19].mean() * N:.0f} (mean over all: {raw[:, 17].mean():.0f})")
 elif raw[:, 17:].any():  # ad-hoc sub-stamps (slots 17..19) of an experiment
