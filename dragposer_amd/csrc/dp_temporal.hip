@@ -66,6 +66,11 @@ struct TArgs {
 };
 
 #define DEV __device__ __forceinline__
+// PAIR (round 6, many sequences): ONE workgroup of 2 NT threads per CU instead of two of NT -- two HALVES, each the NS = 2 workgroup it was (its own
+// LDS arrays, its own two sequences, every phase unchanged) -- so that the feed-forward layers of the calls over at most 8 tokens can share their
+// weight fetches across all four sequences (ffn: COOP).  Every phase indexes by the thread / wave WITHIN ITS HALF:
+DEV int ltid() { return (int)threadIdx.x & (512 - 1); }
+DEV int lwave() { return ((int)threadIdx.x >> 6) & (512 / 64 - 1); }
 
 // Diagnostic build (-DDPT_STAMPS, tools/temporal_phases.sh): thread 0 of workgroup 0 records (phase id, s_memtime) at every phase boundary
 #ifdef DPT_STAMPS
@@ -136,7 +141,7 @@ DEV void lin(float* out, int ldo, const float* in, int ldi, int T, const float* 
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // opaque per call: the per-lane weight addresses are recomputed (a few VALU operations) instead
                                    // of being hoisted out of the layer loops into registers the kernel does not have
-    const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    const int wave = lwave(), l16 = lane & 15, q = lane >> 4;
     const int ntiles = (N + 15) >> 4, jobs = ntiles * n_ttiles<NS>(T, R);
 #pragma unroll 1
     for (int job = wave; job < jobs; job += NWV) {
@@ -178,7 +183,7 @@ DEV void next_token(float* tok, float* preds, const float* x, int T, int it, boo
     const int R = rows_per_seq<NS>(T);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
-    const int wave = threadIdx.x >> 6, l16 = lane & 15, q = lane >> 4;
+    const int wave = lwave(), l16 = lane & 15, q = lane >> 4;
     if (wave < 2) { // two 16-column tiles of the 24 outputs
         const int n = 16 * wave + l16;
         float bw[D / 4], av[D / 4];
@@ -241,7 +246,7 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
     const int R = rows_per_seq<NS>(T);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin: the per-lane addresses of the two parameter rows are not to be hoisted out of the call loop and spilled)
-    const int wave = threadIdx.x >> 6;
+    const int wave = lwave();
     const bool live = lane < D;
     const float gc = live ? g[lane] : 0.f, bc = live ? b[lane] : 0.f;
     const int rows = 16 * n_ttiles<NS>(T, R);
@@ -267,7 +272,7 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
     const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
-    const int wave = threadIdx.x >> 6, l16 = lane & 15, qd = lane >> 4;
+    const int wave = lwave(), l16 = lane & 15, qd = lane >> 4;
     const int ttq = n_ttiles<NS>(Tq, Rq), ttk = n_ttiles<NS>(Tk, Rk), jobs = 3 * ttq + 6 * ttk;
     // a wave takes its jobs two at a time -- job and job + 8 (with nine jobs only wave 0 has a second one): both jobs' operands are requested
     // before the first product (a weight row comes from cold memory: the second round trip is what the other seven waves would wait for)
@@ -327,7 +332,7 @@ DEV void attention(float* ao, const float* q, const float* k, const float* v, fl
     const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
-    const int wave = threadIdx.x >> 6;
+    const int wave = lwave();
     const int h = wave & (NHD - 1), sq = NS == 1 ? 0 : wave / NHD; // NS = 1: waves h and h + 4 share head h; NS = 2: wave = 4 * sequence + head
     constexpr int SHARE = NS == 1 ? NWV / NHD : 1;                  // waves per (sequence, head)
     const int part = NS == 1 ? wave / NHD : 0;
@@ -557,7 +562,7 @@ template <int NS>
 DEV void split_tokens(u4* xs, const float* x, int T, int R)
 {
     const int ntt = n_ttiles<NS>(T, R);
-    int tid = threadIdx.x;
+    int tid = ltid();
     asm volatile("" : "+v"(tid)); // (as in lin: the per-thread addresses are recomputed per call, not hoisted out of the layer loops and held)
     for (int item = tid; item < ntt * 96; item += NT) { // per token tile: 64 lane slots of the full K-block, 32 of the half one
         const int tt = item / 96, r = item - tt * 96, l16 = r & 15, g = r >> 4, ch = 8 * g; // g = 0 .. 3: channels 0 .. 31; g = 4, 5: channels 32 .. 47
@@ -637,15 +642,75 @@ DEV void ffn_p2(const FW2& im, f4 h0, f4 h1, f4 (&acc)[3])
 // TEAM (NS = 1): workgroup g of G takes the tiles g * 8 + wave, + 8 G, ...; its eight waves' partial outputs are summed through LDS as ever, the G
 // workgroups' sums are exchanged as granules (above) and every workgroup adds them up in the same order -- all G hold the same `o` afterwards,
 // bit for bit, which is what lets them run the rest of the block redundantly and in step.
-template <bool PREFETCH, int NS, int R = 16, bool TEAM = false>
+// COOP (PAIR kernels, calls over at most 8 tokens: R = 8): the 16 waves of the two halves deal the tiles among themselves and every tile image
+// serves BOTH halves' token tiles (one each: two sequences of 8 rows) -- half the weight bytes through the CU's L1 per token, which is what bounds
+// these calls (profiles/r05_temporal_phases_1024.txt: 43 k of 49 k cycles per layer are the images' way through the 64 B/clk L1).  `xsb` / `red`
+// are then HALF 0's buffers; half h's lie XS_HALF / RED_HALF further (the kernel declares them as [2][...] arrays: contiguous).
+constexpr int XS_HALF_U4 = NHD * MAXT * MAXT / 4, RED_HALF = 4 * MAXT * D;
+template <bool PREFETCH, int NS, int R = 16, bool TEAM = false, bool COOP = false>
 DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, int l2b, float* red, u4* xsb, Team* tm = nullptr, const FW1* pre = nullptr)
-{ // (xsb: LDS for the tokens' operand rows -- the attention's score buffer, idle here; pre: TEAM -- the image of this wave's first tile, requested by
+{
+    if constexpr (COOP) {
+        static_assert(NS == 2 && R == 8 && !TEAM, "COOP: two halves of two sequences with 8 rows each");
+        const int half = (int)threadIdx.x >> 9, w16 = (int)threadIdx.x >> 6; // my half; my wave among the workgroup's sixteen
+        split_tokens<NS>(xsb + half * XS_HALF_U4, x, T, R);                  // (my half's tokens into my half's buffer; ends with the workgroup's barrier)
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane)); // (as in lin)
+        const int ntiles = (F + FT - 1) / FT;
+        const u4* img = (const u4*)(w + pack) + lane;
+        const u4* xs = xsb + lane;
+        f4 acc[2][3];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) acc[g][ct] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int nt = w16; nt < ntiles; nt += 2 * NWV) {
+            f4 h[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                FW1 w1;
+                ffn_load1(w1, img, nt, ntiles, t);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) h[g][t] = ffn_p1(w1, xs + g * XS_HALF_U4);
+                __builtin_amdgcn_sched_barrier(0); // (the next part's loads are not to be hoisted above this one's products: registers)
+            }
+            FW2 w2;
+            ffn_load2(w2, img, nt, ntiles);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) ffn_p2(w2, h[g][0], h[g][1], acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP(23);
+        // the sixteen waves' partial outputs of token tile g (= half g's), through the two halves' reduction buffers taken as one: sixteen 3 KB slots
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) *(f4*)(red + ((w16 * 3 + ct) * 64 + lane) * 4) = acc[g][ct];
+            __syncthreads();
+            if (half == g) { // (uniform per wave)
+                for (int idx = ltid(); idx < 16 * D; idx += NT) {
+                    const int tl = idx / D, c = idx - tl * D;
+                    if (row_valid<NS>(tl, T, R)) {
+                        const int slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
+                        float sum = w[l2b + c];
+#pragma unroll
+                        for (int wv = 0; wv < 2 * NWV; ++wv) sum += red[wv * 3 * 256 + slot];
+                        o[tl * D + c] = sum;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        STAMP(24);
+        return;
+    } // (xsb: LDS for the tokens' operand rows -- the attention's score buffer, idle here; pre: TEAM -- the image of this wave's first tile, requested by
   //  the caller at the head of the layer: a cold fetch hidden behind the attention; R, the rows per sequence, is a compile-time constant here: as a
   //  run-time value it cost the 128-register instantiation 8 spills)
     split_tokens<NS>(xsb, x, T, R);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
-    const int wave = threadIdx.x >> 6;
+    const int wave = lwave();
     const int ntiles = (F + FT - 1) / FT;
     const u4* img = (const u4*)(w + pack) + lane;
     const u4* xs = xsb + lane;
@@ -731,7 +796,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
                 __syncthreads();
                 continue;
             }
-            for (int idx = threadIdx.x; idx < 16 * D; idx += NT) {
+            for (int idx = ltid(); idx < 16 * D; idx += NT) {
                 const int tl = idx / D, c = idx - tl * D;
                 if (row_valid<NS>(16 * tt + tl, T, R)) {
                     const int slot = (((c >> 4) * 64) + (tl >> 2) * 16 + (c & 15)) * 4 + (tl & 3);
@@ -769,19 +834,27 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 // 256 registers, the next part of a feed-forward tile's image in flight under the current one's products: latency with few).  NS = sequences per workgroup.
 // TEAM (OCC = 2, NS = 1; few sequences): a.G workgroups per sequence.  Every one of them runs the whole block -- same instructions, same data, same
 // bits -- except the feed-forward layers (94 % of the work), where each takes 1/G of the hidden units and the partial sums are exchanged (ffn).
-template <int OCC, int NS, bool TEAM = false>
-__global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
+// PAIR (OCC = 4, NS = 2): one workgroup of 2 NT threads per CU -- two halves, each what the NS = 2 workgroup is, sharing the feed-forward weight
+// fetches of the calls over at most 8 tokens (ffn: COOP).
+template <int OCC, int NS, bool TEAM = false, bool PAIR = false>
+__global__ __launch_bounds__(PAIR ? 2 * NT : NT, PAIR ? 1 : OCC) void dp_temporal_kernel(const TArgs a)
 {
     static_assert(!TEAM || NS == 1, "a team runs one sequence");
-    __shared__ __attribute__((aligned(16))) float mem[MAXT * D], x[MAXT * D], o[MAXT * D]; // (rows are read in 16-byte words: lin)
+    static_assert(!PAIR || (NS == 2 && OCC == 4 && !TEAM), "PAIR: two halves of two sequences each");
+    constexpr int H2 = PAIR ? 2 : 1;
+    const int half = PAIR ? (int)threadIdx.x >> 9 : 0;
+    __shared__ __attribute__((aligned(16))) float mem_[H2][MAXT * D], x_[H2][MAXT * D], o_[H2][MAXT * D]; // (rows are read in 16-byte words: lin)
     // q, k, v and the attention output; dead while the feed-forward block runs, whose cross-wave reduction buffer is the
-    // same 24 KB (70 KB of LDS in all: two workgroups per CU)
-    __shared__ __attribute__((aligned(16))) float qkva[4 * MAXT * D];
-    static_assert(4 * MAXT * D >= NWV * 3 * 64 * 4, "the reduction buffer fits the attention buffers");
+    // same 24 KB (70 KB of LDS in all: two workgroups per CU -- or one of two halves)
+    __shared__ __attribute__((aligned(16))) float qkva_[H2][4 * MAXT * D];
+    static_assert(4 * MAXT * D >= NWV * 3 * 64 * 4 && RED_HALF == NWV * 3 * 64 * 4, "the reduction buffer fits the attention buffers (COOP: exactly, the two halves' make sixteen slots)");
+    float *mem = mem_[half], *x = x_[half], *o = o_[half], *qkva = qkva_[half];
     float *q = qkva, *kb = qkva + MAXT * D, *vb = qkva + 2 * MAXT * D, *ao = qkva + 3 * MAXT * D, *red = qkva;
-    __shared__ __attribute__((aligned(16))) float sc[NHD * MAXT * MAXT], tok[MAXT * LAT], enc_in[MAXT * MAX_IN], preds[NS * (MAXT + 1) * LAT];
-    const int s0 = TEAM ? (int)blockIdx.x / a.G : (int)blockIdx.x * NS, tid = threadIdx.x;
-    if (s0 >= a.n_seq) return;
+    __shared__ __attribute__((aligned(16))) float sc_[H2][NHD * MAXT * MAXT], tok_[H2][MAXT * LAT], enc_in_[H2][MAXT * MAX_IN], preds_[H2][NS * (MAXT + 1) * LAT];
+    static_assert(XS_HALF_U4 * 4 == NHD * MAXT * MAXT, "COOP: the halves' token operand buffers are one array");
+    float *sc = sc_[half], *tok = tok_[half], *enc_in = enc_in_[half], *preds = preds_[half];
+    const int s0 = TEAM ? (int)blockIdx.x / a.G : PAIR ? (int)blockIdx.x * 4 + 2 * half : (int)blockIdx.x * NS, tid = ltid();
+    if (!PAIR && s0 >= a.n_seq) return; // (PAIR: a half without a sequence computes on zeros and stores nothing -- its waves are needed in the shared phases)
     __shared__ int team_dead;
     Team team{};
     if (TEAM) {
@@ -851,7 +924,10 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
         add_ln<NS>(x, o, Te, wl + L.n1w, wl + L.n1b);
         STAMP(4);
         if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc, &team, &pre);
-        else if (rows_per_seq<NS>(Te) == 8) ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc); // (uniform; a history of at most 8 tokens)
+        else if (rows_per_seq<NS>(Te) == 8) { // (uniform; a history of at most 8 tokens)
+            if constexpr (PAIR) ffn<false, NS, 8, false, true>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, qkva_[0], (u4*)sc_[0]);
+            else ffn<OCC == 2, NS, 8>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc);
+        }
         else ffn<OCC == 2, NS, 16>(o, x, Te, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc);
         STAMP(5);
         add_ln<NS>(x, o, Te, wl + L.n2w, wl + L.n2b);
@@ -880,7 +956,10 @@ __global__ __launch_bounds__(NT, OCC) void dp_temporal_kernel(const TArgs a)
             add_ln<NS>(x, o, T, wl + L.n2w, wl + L.n2b);
             STAMP(4);
             if constexpr (TEAM) ffn<true, 1, 16, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc, &team, &pre);
-            else if (rows_per_seq<NS>(T) == 8) ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc); // (uniform)
+            else if (rows_per_seq<NS>(T) == 8) { // (uniform)
+                if constexpr (PAIR) ffn<false, NS, 8, false, true>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, qkva_[0], (u4*)sc_[0]);
+                else ffn<OCC == 2, NS, 8>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc);
+            }
             else ffn<OCC == 2, NS, 16>(o, x, T, w, a.ff, L.ffn_pack, L.lin2_b, red, (u4*)sc);
             STAMP(5);
             add_ln<NS>(x, o, T, wl + L.n3w, wl + L.n3b);
@@ -1171,7 +1250,7 @@ extern "C" int dp_temporal_debug_read_stamps(unsigned long long* out, int cap)
 extern "C" int dp_temporal_debug_force_variant(dp_temporal* t, int variant)
 {
     // (102, 104, 108, 116: a team of 2 / 4 / 8 / 16 workgroups per sequence where the launch fits the device, else as 0)
-    if (!t || (variant != 0 && variant != 21 && variant != 41 && variant != 42 && variant != 102 && variant != 104 && variant != 108 && variant != 116)) return DP_ERR_INVALID;
+    if (!t || (variant != 0 && variant != 21 && variant != 41 && variant != 42 && variant != 44 && variant != 102 && variant != 104 && variant != 108 && variant != 116)) return DP_ERR_INVALID;
     t->forced_variant = variant;
     return DP_OK;
 }
@@ -1248,7 +1327,12 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     // variant: few sequences -> latency (one workgroup per CU, prefetch); many -> two workgroups per CU, and two sequences per
     // workgroup when each has at most 16 tokens (every weight fetch then serves both)
     const bool pair_ok = n_past - 1 <= 16 && n_steps <= 16;
-    int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? 42 : 41);
+    // (44 = PAIR, one 1024-thread workgroup of two NS = 2 halves per CU that share the weight fetches of the feed-forward layers in calls over at
+    //  most 8 tokens.  Measured at 1024 / 4096 sequences, profiles/r06_temporal_pair_ab.txt: window 16 (five decoder calls of 1 .. 5 tokens) -11.5 %;
+    //  window 0 and window 60 +-1 % -- what the shared fetches save there, the halves' lock-step gives back: two independent workgroups on a CU
+    //  drift apart and run one's small phases under the other's tile loop.  So: where EVERY decoder call has at most 8 tokens and there are at least
+    //  two of them, and variant 42 would put two workgroups on a CU anyway.)
+    int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? ((n_seq > 2 * t->n_cu && n_steps >= 2 && n_steps <= 8) ? 44 : 42) : 41);
     // few sequences: a TEAM of G workgroups per sequence (the largest power of two up to 16 with every workgroup on a CU of its own -- they wait for
     // each other, so all of them must be resident -- and at least one feed-forward tile per wave)
     // (the CUs this launch may use: the device's, or the stream's CU mask when it has one -- hipExtStreamGetCUMask reports the effective mask)
@@ -1269,7 +1353,7 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
         G = G >= want ? want : 1;
     }
     if (G >= 2 && (t->forced_variant == 0 || t->forced_variant >= 100)) variant = 100 + G;
-    if (t->forced_variant == 21 || t->forced_variant == 41 || (t->forced_variant == 42 && pair_ok)) variant = t->forced_variant;
+    if (t->forced_variant == 21 || t->forced_variant == 41 || ((t->forced_variant == 42 || t->forced_variant == 44) && pair_ok)) variant = t->forced_variant;
     if (variant >= 100) {
         const int max_teams = t->n_cu / 2 > 0 ? t->n_cu / 2 : 1;
         a.G = G; a.xch = t->d_xch; a.epochs = (unsigned*)((char*)t->d_xch + t->xch_granule_bytes); a.tstatus = (int*)(a.epochs + max_teams);
@@ -1277,6 +1361,7 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
         hipLaunchKernelGGL((dp_temporal_kernel<2, 1, true>), dim3(n_seq * G), dim3(NT), 0, (hipStream_t)stream, a);
     } else if (variant == 21) hipLaunchKernelGGL((dp_temporal_kernel<2, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
     else if (variant == 41) hipLaunchKernelGGL((dp_temporal_kernel<4, 1>), dim3(n_seq), dim3(NT), 0, (hipStream_t)stream, a);
+    else if (variant == 44) hipLaunchKernelGGL((dp_temporal_kernel<4, 2, false, true>), dim3((n_seq + 3) / 4), dim3(2 * NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dp_temporal_kernel<4, 2>), dim3((n_seq + 1) / 2), dim3(NT), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);

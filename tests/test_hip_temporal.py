@@ -36,9 +36,10 @@ def _torch_block(model, means, stds, lat, disp, hts, window):
 
 
 # the kernel variants (waves per SIMD, sequences per workgroup): 21 = one workgroup per CU with prefetch (few sequences),
-# 41 = two workgroups per CU, 42 = two per CU with two sequences each (many sequences of at most 16 tokens)
+# 41 = two workgroups per CU, 42 = two per CU with two sequences each (many sequences of at most 16 tokens), 44 = ONE workgroup of 1024 threads per
+# CU: two halves of two sequences each that share the feed-forward weight fetches of the calls over at most 8 tokens (round 6)
 # 102 ... 116: a TEAM of 2 ... 16 workgroups per sequence (what few sequences get: each takes 1 / G of every feed-forward layer)
-@pytest.mark.parametrize("variant", [21, 41, 42, 102, 104, 108, 116])
+@pytest.mark.parametrize("variant", [21, 41, 42, 44, 102, 104, 108, 116])
 @pytest.mark.parametrize("window", [0, 16, 60])
 def test_native_predictor_matches_nn_transformer_at_full_size(window, variant):
     from dragposer_amd.temporal import NativeTemporal, TemporalPredictor
