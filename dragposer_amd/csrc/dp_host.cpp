@@ -601,6 +601,13 @@ static int take_params(dp_ctx* ctx, const dp_params* p, dp_params& o, const char
         return fail(ctx, DP_ERR_INVALID, std::string(who) + ": dp_params.struct_size is " + std::to_string(p->struct_size) + ", this library (DP_VERSION " +
                                              std::to_string(DP_VERSION) + ") expects at least " + std::to_string(PARAMS_SIZE_V500) +
                                              " -- was the caller compiled against a pre-0.5 dragposer.h?  (dp_params p = DP_PARAMS_INIT;)");
+    // A 0.4 caller's struct is 52 bytes and starts with n_iter: one that asks for 56 ... 4096 iterations passes the size test above.  Its SECOND word is
+    // `lr`, whose bits read as an iteration count are beyond DP_MAX_ITERS for any learning rate above 1.4e-39 -- tested HERE, on the two words every
+    // layout has, before anything is copied: the 52-byte struct is never read past.
+    if (p->n_iter < 1 || p->n_iter > DP_MAX_ITERS)
+        return fail(ctx, DP_ERR_INVALID, std::string(who) + ": n_iter " + std::to_string(p->n_iter) + " out of range [1, DP_MAX_ITERS] (dp_params.struct_size " +
+                                             std::to_string(p->struct_size) + ": if that is the iteration count you meant, the caller was compiled against a pre-0.5 "
+                                             "dragposer.h, whose dp_params starts with n_iter; dp_params p = DP_PARAMS_INIT;)");
     std::memset(&o, 0, sizeof(o));
     std::memcpy(&o, p, std::min<size_t>(p->struct_size, sizeof(o)));
     return DP_OK;

@@ -652,7 +652,7 @@ DEV void ffn(float* o, const float* x, int T, const float* w, int F, int pack, i
 {
     if constexpr (COOP) {
         static_assert(NS == 2 && R == 8 && !TEAM, "COOP: two halves of two sequences with 8 rows each");
-        const int half = (int)threadIdx.x >> 9, w16 = (int)threadIdx.x >> 6; // my half; my wave among the workgroup's sixteen
+        const int w16 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = w16 >> 3; // my wave among the workgroup's sixteen; my half (uniform)
         split_tokens<NS>(xsb + half * XS_HALF_U4, x, T, R);                  // (my half's tokens into my half's buffer; ends with the workgroup's barrier)
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane)); // (as in lin)
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(PAIR ? 2 * NT : NT, PAIR ? 1 : OCC) void dp_tempora
     static_assert(!TEAM || NS == 1, "a team runs one sequence");
     static_assert(!PAIR || (NS == 2 && OCC == 4 && !TEAM), "PAIR: two halves of two sequences each");
     constexpr int H2 = PAIR ? 2 : 1;
-    const int half = PAIR ? (int)threadIdx.x >> 9 : 0;
+    const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 9) : 0; // (uniform per wave: the halves' array bases stay in scalar registers)
     __shared__ __attribute__((aligned(16))) float mem_[H2][MAXT * D], x_[H2][MAXT * D], o_[H2][MAXT * D]; // (rows are read in 16-byte words: lin)
     // q, k, v and the attention output; dead while the feed-forward block runs, whose cross-wave reduction buffer is the
     // same 24 KB (70 KB of LDS in all: two workgroups per CU -- or one of two halves)

@@ -124,8 +124,9 @@ typedef struct dp_batch {
 
 typedef struct dp_params {
     unsigned struct_size; /* sizeof(dp_params) in the caller's translation unit (DP_PARAMS_INIT sets it).  The library refuses a
-                             value below the 0.5.0 size (a 0.4 caller's first word is n_iter <= 256: always refused) and reads no
-                             field beyond it */
+                             value below the 0.5.0 size and reads no field beyond it.  A 0.4 caller's first word is n_iter: below 56 it
+                             fails this test; from 56 on the second word -- its `lr` -- is read as n_iter, which is beyond DP_MAX_ITERS
+                             for every learning rate above 1.4e-39 and refused before anything else of the struct is touched */
     int n_iter;        /* max_iter; exactly n_iter iterations when early_stop == 0 (1 .. DP_MAX_ITERS) */
     float lr;          /* learning_rate */
     float beta1, beta2, eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8.  eps must be > 0 (DP_ERR_INVALID otherwise): torch accepts 0,

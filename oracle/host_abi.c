@@ -109,6 +109,8 @@ int dp_optimize(dp_ctx* ctx, const dp_batch* in, const dp_params* p, const dp_re
     if (!in || !p) return fail(ctx, DP_ERR_INVALID, "dp_optimize: NULL batch/params");
     /* the refusals of dp_host.cpp (take_params / take_result): a struct compiled against another header is detected by its size word */
     if (p->struct_size < sizeof(dp_params) || p->struct_size > 4096u) return fail(ctx, DP_ERR_INVALID, "dp_optimize: dp_params.struct_size (pre-0.5 dragposer.h?)");
+    /* (a 0.4 struct whose n_iter is 56 .. 4096 passes the size test: its second word is lr, an absurd iteration count -- refused before anything else is read) */
+    if (p->n_iter < 1 || p->n_iter > DP_MAX_ITERS) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_iter out of range [1, DP_MAX_ITERS] (or dp_params.struct_size is a pre-0.5 caller's n_iter)");
     if (out && (out->struct_size < sizeof(dp_result) || out->struct_size > 4096u || out->reserved0 != 0u))
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: dp_result.struct_size (pre-0.5 dragposer.h?)");
     if (in->n_frames <= 0) return fail(ctx, DP_ERR_INVALID, "dp_optimize: n_frames must be positive");

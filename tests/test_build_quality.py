@@ -72,12 +72,13 @@ def test_temporal_kernel_variants_fit_their_occupancy(tmp_path):
     notes = _kernel_notes("dp_temporal.hip", tmp_path)
     kernels = {k: v for k, v in notes.items() if "dp_temporal_kernel" in k}
     # <2, 1> (one workgroup per CU), <2, 1, TEAM> (few sequences: G workgroups per sequence), <4, 1> and <4, 2> (two workgroups per CU; one / two sequences each)
-    assert len(kernels) == 4, list(notes)
+    # ... and <4, 2, PAIR> (round 6: ONE 1024-thread workgroup of two <4, 2> halves per CU, twice the LDS)
+    assert len(kernels) == 5, list(notes)
     for name, n in kernels.items():
         assert n["vspill"] == 0 and n["scratch"] == 0, (name, n)
-        team = "ILi2ELi1ELb1EE" in name                  # (a team's workgroups have a CU each: n_seq * G <= CUs)
-        assert n["lds"] <= (160 if team else 80) * 1024, (name, n)  # the others: two workgroups per CU
-    assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, False, True, True]  # the 2-waves-per-SIMD variants use the full file
+        one_per_cu = "ILi2ELi1ELb1ELb0EE" in name or "ILi4ELi2ELb0ELb1EE" in name  # (a team's workgroups have a CU each: n_seq * G <= CUs / 2; a PAIR workgroup is the CU's only one)
+        assert n["lds"] <= (160 if one_per_cu else 80) * 1024, (name, n)  # the others: two workgroups per CU
+    assert sorted(n["vgpr"] <= 128 for n in kernels.values()) == [False, False, True, True, True]  # the 2-waves-per-SIMD variants use the full file
 
 
 @pytest.mark.parametrize("src, one_wave", [("dp_w16.hip", True), ("dp_w16_es.hip", True), ("dp_w16_2w.hip", False), ("dp_w16_2w_es.hip", False)])

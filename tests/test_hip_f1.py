@@ -84,7 +84,9 @@ def test_cli_against_the_reference_run_of_the_clip(golden_dir, tmp_path, name):
     #  apart in this window -- a 1e-6 difference in z_tgt is 0.1 mm in the legs after frame 4's 23 iterations: 0.056 mm with the predictor's first
     #  K-step order, 0.138 mm with the one of round 5's latency work, 0.018 mm with the feed-forward layers in split precision on the bf16 pipe --
     #  the same predictor to 1e-6 each time, iteration counts equal every time.  Fewer than six trackers: the strict window's bar)
-    assert same[:8].all() and d[:8].max() <= (0.05 if six else 0.2) and dg[:8].max() <= 0.05, (iters[:8], g["iters"][:8], d[:8].max())
+    # (the looser bars are the 4-tracker clips' BY NAME: f1_clip3 / f1_clip3_t passed at 0.05 mm / 5e-3 / rtol 0.25 before those clips existed and still do)
+    four = name.startswith("f1_clip4")
+    assert same[:8].all() and d[:8].max() <= (0.2 if four else 0.05) and dg[:8].max() <= 0.05, (iters[:8], g["iters"][:8], d[:8].max())
     assert same[:STRICT].all() and d[:STRICT].max() <= 0.2, (iters[:STRICT], g["iters"][:STRICT], d[:STRICT].max())
     # after the strict window: no farther from the reference than three times what the reference's own twin run is (per frame range;
     # a floor of 10 mm where the twin happened to stay together), sequence-level figures within 5 % or three times the twins' spread
@@ -102,7 +104,7 @@ def test_cli_against_the_reference_run_of_the_clip(golden_dir, tmp_path, name):
         assert d[:32].max() <= 1.0, d[:32].max()
         # (the 4-tracker clip without the pull term, profiles/r05_clip_twins.txt: the product's OWN runs from initial latents 1e-7 ... 1e-4 apart
         #  give MPEEPE 50 ... 71 mm at 1.7 ... 3.5 iterations per frame, the reference and its twin 80 / 73 mm at 4.1 / 3.3: a chaotic loop, one regime)
-        np.testing.assert_allclose([res["mpjpe"], res["mpeepe"]], [float(g["mpjpe"]), float(g["mpeepe"])], rtol=max(0.35, 3.0 * spread))
+        np.testing.assert_allclose([res["mpjpe"], res["mpeepe"]], [float(g["mpjpe"]), float(g["mpeepe"])], rtol=max(0.35 if four else 0.25, 3.0 * spread))
     assert abs(iters.mean() - g["iters"].mean()) <= max(0.1, 3.0 * abs(g["twin_iters"].mean() - g["iters"].mean()) / g["iters"].mean()) * g["iters"].mean() + 1.5
     assert same.mean() >= 0.5 * same_t.mean()
     # the written file: on the strict window, the reference's MOTION block
@@ -110,7 +112,7 @@ def test_cli_against_the_reference_run_of_the_clip(golden_dir, tmp_path, name):
     dm = np.abs(mine[:STRICT] - g["result_motion_all"][:STRICT])
     dm[:, 3:] = np.minimum(dm[:, 3:], np.abs(dm[:, 3:] - 360.0))
     print(f"{name}: MOTION block against the reference's, strict window: first 8 frames {dm[:8].max():.2e}, all {dm.max():.2e} (degrees / metres)")
-    assert dm[:8].max() <= (5e-3 if six else 5e-2) and dm.max() <= 5e-2, (dm[:8].max(), dm.max())  # degrees / metres as printed (6 decimals)
+    assert dm[:8].max() <= (5e-2 if four else 5e-3) and dm.max() <= 5e-2, (dm[:8].max(), dm.max())  # degrees / metres as printed (6 decimals)
 
 
 def test_cli_on_the_whole_example_file_against_the_reference_run(golden_dir, tmp_path):

@@ -161,6 +161,14 @@ def test_a_struct_compiled_against_another_header_is_refused(lib, golden_dir):
     p.struct_size = 50  # a 0.4 dp_params: n_iter = 50 in the first word
     assert lib.dp_optimize(ctx, C.byref(b), C.byref(p), C.byref(r), None) == _lib.DP_ERR_INVALID
     assert b"struct_size" in lib.dp_last_error(ctx)
+    # a 0.4 dp_params that asks for 100 iterations (the sequence default): 13 words = 52 bytes, n_iter first.  100 passes for a size; the second
+    # word is lr = 0.01, an iteration count of 1 008 981 770: refused on the two words every layout has, before anything is copied
+    old = (C.c_uint32 * 13)()
+    words = np.array([100, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], np.uint32)
+    words[1:7] = np.array([1e-2, 0.9, 0.999, 1e-8, 1.0, 0.02], np.float32).view(np.uint32)
+    old[:] = [int(w) for w in words]
+    assert lib.dp_optimize(ctx, C.byref(b), C.cast(old, C.POINTER(_lib.DpParams)), C.byref(r), None) == _lib.DP_ERR_INVALID
+    assert b"n_iter" in lib.dp_last_error(ctx) and b"pre-0.5" in lib.dp_last_error(ctx)
     p.struct_size = C.sizeof(_lib.DpParams)
     r.struct_size, r.reserved0 = 0x1a2b3c40, 0x7f12  # a 0.4 dp_result: the two halves of a device pointer
     assert lib.dp_optimize(ctx, C.byref(b), C.byref(p), C.byref(r), None) == _lib.DP_ERR_INVALID
