@@ -712,10 +712,8 @@ extern "C" int dp_optimize_debug(dp_ctx* ctx, const dp_batch* in, const dp_param
         return fail(ctx, DP_ERR_INVALID, "dp_optimize: unknown kernel selector");
     if (p->kernel == DP_KERNEL_W16 && !w16_can)
         return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 is laid out for the reference's 22-joint skeleton only");
-    // beyond the argument table of Adam scalars (n_iter > 256) only dp_w4 has instantiations that continue them on the device (dp_w4.hip: LONG)
-    if (p->kernel == DP_KERNEL_W16 && p->n_iter > MAX_ITERS)
-        return fail(ctx, DP_ERR_UNSUPPORTED, "dp_optimize: DP_KERNEL_W16 takes n_iter <= 256 (more iterations: DP_KERNEL_AUTO or DP_KERNEL_W4)");
-    const int kernel = p->kernel == DP_KERNEL_AUTO ? (p->n_iter > MAX_ITERS ? DP_KERNEL_W4 : dp_auto_kernel(ctx, in->n_frames)) : p->kernel;
+    // (beyond the argument table of Adam scalars, n_iter > 256, both kernels have LONG instantiations that continue them on the device)
+    const int kernel = p->kernel == DP_KERNEL_AUTO ? dp_auto_kernel(ctx, in->n_frames) : p->kernel;
     return launch(ctx, k, stream, kernel);
 }
 

@@ -10,8 +10,11 @@ extern "C" hipError_t dp_launch_w16_2w(const KArgs* args, hipStream_t stream);
 extern "C" hipError_t dp_launch_w16_es(const KArgs* args, hipStream_t stream);
 extern "C" hipError_t dp_launch_w16_2w_es(const KArgs* args, hipStream_t stream);
 
+extern "C" hipError_t dp_launch_w16_long(const KArgs* args, hipStream_t stream, int waves); // n_iter beyond the argument table (dp_w16_long.hip)
+
 extern "C" hipError_t dp_launch_w16(const KArgs* args, hipStream_t stream, int waves)
 {
+    if (args->n_iter > MAX_ITERS) return dp_launch_w16_long(args, stream, waves);
     if (args->early_stop) return waves == 8 ? dp_launch_w16_2w_es(args, stream) : dp_launch_w16_es(args, stream);
     if (waves == 8) return dp_launch_w16_2w(args, stream);
     const int grid = (args->n_frames + 4 * FPW - 1) / (4 * FPW);

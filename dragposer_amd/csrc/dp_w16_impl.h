@@ -35,7 +35,8 @@ constexpr int L16_BIAS = L16_IMG + IMG_U32;
 constexpr int L16_TAB = L16_BIAS + BIAS_FLOATS; // per-iteration Adam scalars [MAX_ITERS][2]
 constexpr int L16_FLAGS = L16_TAB + 2 * MAX_ITERS; // [8 waves][16 frames] DP_STATUS_BAD_* of the input screening, parked for the epilogue
 constexpr int L16_CLK = L16_FLAGS + 8 * FPW;       // [4] the two start stamps of dp_result.clock (64 bits each)
-constexpr int L16_END = L16_CLK + 4;
+constexpr int L16_ADX = L16_CLK + 4;               // [8 waves][2 doubles] Adam's running products beyond the argument table (LONG instantiations: adam_beyond)
+constexpr int L16_END = L16_ADX + 8 * 4;
 
 // ---------------------------------------------------------------- small vector helpers
 DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -197,7 +198,10 @@ DEV f4 bias_row(const float* lds_bias, int tile, int g) { return *(const f4*)(ld
 // takes this one last step (its final latent) and then keeps its pre-step latent, so that the forward passes it still takes part in
 // reproduce its last one; a wave leaves the loop once all sixteen of its frames have stopped.  A frame is a lane column here, its
 // state replicated over the four lane groups.
-template <int NW, int WPS, bool EARLY = false>
+// LONG: n_iter beyond the kernel-argument table of Adam scalars (MAX_ITERS; the reference has no cap on max_iter): one uniform branch per iteration
+// continues the two bias corrections in double on the device (adam_beyond), as dp_w4's LONG instantiations do.  Their own translation units
+// (dp_w16_long*.hip): the ordinary launches' code is untouched.
+template <int NW, int WPS, bool EARLY = false, bool LONG = false>
 __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[L16_END];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     // ---- set-up: the weight image, bias rows and the Adam table into LDS (once per workgroup)
     for (int k = tid; k < IMG_U32 / 4; k += NW * 64) ((u4*)(lds + L16_IMG))[k] = ((const u4*)a.w16img)[k];
     for (int k = tid; k < BIAS_FLOATS; k += NW * 64) ((float*)lds)[L16_BIAS + k] = a.w16bias[k];
-    for (int k = tid; k < a.n_iter; k += NW * 64) *(f2*)((float*)lds + L16_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]}; // (n_iter <= MAX_ITERS: dp_host.cpp)
+    for (int k = tid; k < min(a.n_iter, MAX_ITERS); k += NW * 64) *(f2*)((float*)lds + L16_TAB + 2 * k) = f2{a.tab.step[k], a.tab.bc2s[k]}; // (beyond the table: LONG)
 
     // latent and Adam state in the D layout: tile n, register r = latent dim 16 n + 4 g + r (dims 24..31: zero, stay zero)
     f4 z[2], zt[2], mA[2], vA[2];
@@ -334,9 +338,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     int es_iters = 0;
     f4 zfin[2] = {z[0], z[1]};
 
+    if constexpr (LONG) { double* adx = (double*)(lds + L16_ADX) + 2 * wave; adx[0] = a.cont.b1t; adx[1] = a.cont.b2t; } // (every lane the same values: adam_beyond)
     for (int iter = 0; iter < a.n_iter; ++iter) {
         const bool last = iter == a.n_iter - 1;
-        const f2 adam_t = *(const f2*)((const float*)lds + L16_TAB + 2 * iter);
+        f2 adam_t = *(const f2*)((const float*)lds + L16_TAB + 2 * (LONG ? min(iter, MAX_ITERS - 1) : iter));
+        if constexpr (LONG) {
+            if (iter >= MAX_ITERS) { // (uniform: beyond the argument table)
+                float st_ = 0.f, rb_ = 0.f;
+                adam_beyond((double*)(lds + L16_ADX) + 2 * wave, a.cont, st_, rb_);
+                adam_t = f2{st_, rb_};
+            }
+        }
         int o0 = lane, o1 = lane + 4096, o2 = lane + 8192;
         asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2)); // opaque per iteration: the weight reads stay inside the loop
         const Img img = {{(const u4*)(lds + L16_IMG) + o0, (const u4*)(lds + L16_IMG) + o1, (const u4*)(lds + L16_IMG) + o2}};

@@ -149,7 +149,7 @@ typedef struct dp_params {
  *                  early stop; the reference's 22-joint skeleton only (DP_ERR_UNSUPPORTED otherwise).  Pays when W4 needs a THIRD round
  *                  (W4 holds 16 frames per CU at a time: 4096 on an MI355X; it runs two rounds in 0.25 ms, W16 any batch up to 16 384
  *                  frames in 0.27-0.28 ms).
- *                  n_iter <= 256 (the kernel-argument table of Adam scalars; beyond it: DP_ERR_UNSUPPORTED, DP_KERNEL_AUTO takes W4 then).
+ *                  (Until 0.5.1 it took n_iter <= 256 only, the kernel-argument table of Adam scalars; it continues them on the device now, as W4 does.)
  *   DP_KERNEL_AUTO W16 for more than 32 frames per CU (> 8192 on an MI355X; > 4096 before 0.5.0), either weight type, with or without early stop (both
  *                  kernels compute in fp32-equivalent arithmetic and are held to the same reference runs,
  *                  tests/test_hip_parity.py::test_full_size_batch_properties, tests/test_hip_w16.py); W4 otherwise -- BASELINE's

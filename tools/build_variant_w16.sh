@@ -15,5 +15,5 @@ if [ "${ES:-1}" != "0" ]; then
   hipcc $FLAGS $3 -c dragposer_amd/csrc/dp_w16_2w_es.hip -o _scratch/dp_w16_2w_es_$1.o
   ES1=_scratch/dp_w16_es_$1.o; ES2=_scratch/dp_w16_2w_es_$1.o
 fi
-hipcc --offload-arch=gfx950 -shared -fPIC -o _scratch/lib_$1.so $B/dp_host.o $B/dp_w16_host.o $B/dp_w4.o _scratch/dp_w16_$1.o _scratch/dp_w16_2w_$1.o $ES1 $ES2 $B/dp_sequence.o $B/dp_temporal.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o _scratch/lib_$1.so $B/dp_host.o $B/dp_w16_host.o $B/dp_w4.o _scratch/dp_w16_$1.o _scratch/dp_w16_2w_$1.o $ES1 $ES2 $B/dp_w16_long.o $B/dp_w16_2w_long.o $B/dp_w16_es_long.o $B/dp_w16_2w_es_long.o $B/dp_sequence.o $B/dp_temporal.o
 echo _scratch/lib_$1.so

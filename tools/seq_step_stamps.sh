@@ -7,7 +7,7 @@ mkdir -p _scratch
 B=dragposer_amd/csrc/_build
 FLAGS=$(python3 -c "import __graft_entry__ as g; print(' '.join(f for f in g.HIPCC_FLAGS if f != '-shared'))")
 hipcc $FLAGS -DDP_SEQ_STAMPS -c dragposer_amd/csrc/dp_w4.hip -o _scratch/dp_w4_stamps.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o _scratch/lib_seqstamps.so $B/dp_host.o $B/dp_w16_host.o _scratch/dp_w4_stamps.o $B/dp_w16.o $B/dp_w16_2w.o $B/dp_w16_es.o $B/dp_w16_2w_es.o $B/dp_sequence.o $B/dp_temporal.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o _scratch/lib_seqstamps.so $B/dp_host.o $B/dp_w16_host.o _scratch/dp_w4_stamps.o $B/dp_w16.o $B/dp_w16_2w.o $B/dp_w16_es.o $B/dp_w16_2w_es.o $B/dp_w16_long.o $B/dp_w16_2w_long.o $B/dp_w16_es_long.o $B/dp_w16_2w_es_long.o $B/dp_sequence.o $B/dp_temporal.o
 python3 - <<'PY' 2>&1 | grep -v amdgpu.ids
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
