@@ -121,7 +121,7 @@ class DpResult(_Sized):
     ]
 
 
-DP_STATUS_NONFINITE_RESULT, DP_STATUS_BAD_STATE, DP_STATUS_BAD_TARGETS = 1, 2, 4
+DP_STATUS_NONFINITE_RESULT, DP_STATUS_BAD_STATE, DP_STATUS_BAD_TARGETS, DP_STATUS_TARGET_NOT_ROTATION = 1, 2, 4, 8
 DP_TEMPORAL_TEAM_TIMEOUT = 1
 DP_INPUT_LIMIT = 1.0e4
 

@@ -72,6 +72,18 @@ DEV void adam_beyond(double* st, const AdamCont& c, float& step, float& rbc2s)
     rbc2s = (float)(1.0 / sqrt(1.0 - b2));
 }
 
+// include/dragposer.h, DP_STATUS_TARGET_NOT_ROTATION: the kernels turn a tracked joint's 3 x 3 target into a unit quaternion once per launch (the
+// reference's element-wise MSE on matrices, drag_pose.py:121-124, equals the quaternion form for ROTATIONS only) -- where it is turned, R^T R is
+// three norms and three dot products away: rows orthonormal within DP_ROTATION_TOL, or the frame says so in its status word.  (NaN fails every <=.)
+DEV bool not_rotation(const float* m)
+{
+    const float n0 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2], n1 = m[3] * m[3] + m[4] * m[4] + m[5] * m[5], n2 = m[6] * m[6] + m[7] * m[7] + m[8] * m[8];
+    const float d01 = m[0] * m[3] + m[1] * m[4] + m[2] * m[5], d02 = m[0] * m[6] + m[1] * m[7] + m[2] * m[8], d12 = m[3] * m[6] + m[4] * m[7] + m[5] * m[8];
+    const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    const float tol = DP_ROTATION_TOL;
+    return !(fabsf(n0 - 1.f) <= tol && fabsf(n1 - 1.f) <= tol && fabsf(n2 - 1.f) <= tol && fabsf(d01) <= tol && fabsf(d02) <= tol && fabsf(d12) <= tol && det > 0.f);
+}
+
 DEV float lrelu(float x) { return fmaxf(x, 0.2f * x); }
 DEV float dlrelu(float a, float g) { return a > 0.f ? g : 0.2f * g; } // torch: x > 0 ? g : g*slope
 

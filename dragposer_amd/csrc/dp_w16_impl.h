@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     // target (z_tgt) set to NaN -- and the arithmetic then does what the reference's does (NaN loss on the first pass, the while-condition
     // fails, Adam writes NaN into the latent).  Inputs beyond DP_INPUT_LIMIT are treated the same way, as dp_w4 treats them.
     const auto oor = [](float x) { return !(fabsf(x) <= DP_INPUT_LIMIT); };
-    float bad_s = (oor(cv.x) || oor(cv.y) || oor(cv.z) || oor(cv.w)) ? 1.f : 0.f, bad_t = 0.f;
+    float bad_s = (oor(cv.x) || oor(cv.y) || oor(cv.z) || oor(cv.w)) ? 1.f : 0.f, bad_t = 0.f, not_r = 0.f;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
 #pragma unroll
             for (int k = 0; k < 9; ++k) bd = bd || oor(m9[k]);
             bad_t += trk && bd ? 1.f : 0.f;
+            not_r += trk && !bd && not_rotation(m9) ? 1.f : 0.f; // (DP_STATUS_TARGET_NOT_ROTATION: reported, computed as given)
         }
         tp[t] = sel3(trk, rot_qc(cur, V3{p[0], p[1], p[2]}), V3{0.f, 0.f, 0.f});
         qT[t] = sel4(trk, quat_mul(qconj(cur), q_from_rotmat(m9)), Q4{1.f, 0.f, 0.f, 0.f});
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
     // (the two flags go to LDS for the epilogue: held in registers across the loop they cost the one-wave unit two spills)
     {
         const bool state_bad = sum_groups(bad_s) > 0.f, tgt_bad = !state_bad && sum_groups(bad_t) > 0.f; // (the same in the frame's four lanes)
-        if (g == 0) lds[L16_FLAGS + wave * FPW + f] = (state_bad ? DP_STATUS_BAD_STATE : 0) + (tgt_bad ? DP_STATUS_BAD_TARGETS : 0);
+        const bool rot_bad = !state_bad && !tgt_bad && sum_groups(not_r) > 0.f;
+        if (g == 0) lds[L16_FLAGS + wave * FPW + f] = (state_bad ? DP_STATUS_BAD_STATE : 0) + (tgt_bad ? DP_STATUS_BAD_TARGETS : 0) + (rot_bad ? DP_STATUS_TARGET_NOT_ROTATION : 0);
     if (__ballot(state_bad || tgt_bad) != 0ull) { // (uniform, rare)
         const float qnan = __builtin_nanf("");
 #pragma unroll
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void dp_w16_kernel(const KArgs a)
         lt = sum_groups(lt) * a.lam_tmp * (1.f / 24.f);
     }
     const int bad_flags = (int)lds[L16_FLAGS + wave * FPW + f]; // (written by this wave's own lanes before the set-up's barrier)
-    if (bad_flags != 0) lsum_p = lsum_r = lt = __builtin_nanf(""); // (the reference's total loss is NaN there; which of its terms are depends on the input)
+    if ((bad_flags & (DP_STATUS_BAD_STATE | DP_STATUS_BAD_TARGETS)) != 0) lsum_p = lsum_r = lt = __builtin_nanf(""); // (the reference's total loss is NaN there; which of its terms are depends on the input)
     if (a.status) { // (uniform)
         float nf = 0.f;
 #pragma unroll

@@ -974,10 +974,17 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     if (SEQ && tid == 0) stage_step_args(lds, a);
     // ---- input screening (out_of_range above): which of my wave's four frames cannot be optimised, and their neutral stand-ins
     unsigned bad_state = 0u, bad_tgt = 0u; // bit r: frame f0 + r (uniform per wave).  state: z0 / cur_rot; tgt: targets, weights, z_tgt
+    unsigned not_rot = 0u;                 // bit r: a tracked target of frame f0 + r is not a rotation matrix (DP_STATUS_TARGET_NOT_ROTATION: reported, computed as given)
     {
         bool tb = !SEQ && raw_bad(raw); // (SEQ: every step screens its own targets, in the step loop)
+        bool nr = !SEQ && raw.act && not_rotation(raw.m);
         if (!SEQ)
-            for (int base = 16; base < Emax; base += 16) tb = tb || raw_bad(tracker_fetch(a, true, gfi, tmask, E, base + b)); // (uniform, rare)
+            for (int base = 16; base < Emax; base += 16) { // (uniform, rare)
+                const TRaw rx = tracker_fetch(a, true, gfi, tmask, E, base + b);
+                tb = tb || raw_bad(rx);
+                nr = nr || (rx.act && not_rotation(rx.m));
+            }
+        not_rot = frames_of(__ballot(nr && !tb)); // (a non-finite target is DP_STATUS_BAD_TARGETS, not this)
         const bool cb = out_of_range(cv.x) || out_of_range(cv.y) || out_of_range(cv.z) || out_of_range(cv.w);
         bad_tgt = frames_of(__ballot(tb));
         bad_state = frames_of(__ballot(cb));
@@ -1144,8 +1151,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
             bad_state |= bad_tgt;
             {
                 bool tb = raw_bad(rs) || out_of_range(step_shift.x) || out_of_range(step_shift.y) || out_of_range(step_shift.z);
-                for (int base = 16; base < Emax; base += 16) tb = tb || raw_bad(tracker_fetch(as, true, gfi, tmask, E, base + b, gft)); // (uniform, rare)
+                bool nr = rs.act && not_rotation(rs.m);
+                for (int base = 16; base < Emax; base += 16) { // (uniform, rare)
+                    const TRaw rx = tracker_fetch(as, true, gfi, tmask, E, base + b, gft);
+                    tb = tb || raw_bad(rx);
+                    nr = nr || (rx.act && not_rotation(rx.m));
+                }
                 bad_tgt = frames_of(__ballot(tb));
+                not_rot = frames_of(__ballot(nr && !tb));
 #pragma unroll
                 for (int r = 0; r < FPW; ++r) bad_tgt |= (__ballot(lane < LAT && out_of_range(ztD[r])) != 0ull ? 1u : 0u) << r;
                 bad_tgt &= ~bad_state;
@@ -1456,7 +1469,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     const auto& ae = step_args_of<SEQ>(a, lds);
     // frames that failed the input screening: what the reference returns for them (include/dragposer.h: DP_STATUS_*) -- everything NaN when the
     // state was bad; z and the loss NaN when the targets were, and the pose results too unless the frame stopped after its first pass
-    asm volatile("" : "+s"(bad_state), "+s"(bad_tgt)); // (opaque here: what the epilogue derives from them per lane is not to be computed ahead of the loop and held across it)
+    asm volatile("" : "+s"(bad_state), "+s"(bad_tgt), "+s"(not_rot)); // (opaque here: what the epilogue derives from them per lane is not to be computed ahead of the loop and held across it)
     const unsigned pois_z = bad_state | bad_tgt, pois_all = bad_state | ((EARLY || ae.n_iter == 1) ? 0u : bad_tgt);
     int row0 = SEQ ? step * nB : 0; // SEQ: this step's slab of the per-step output arrays
     int gfo = row0 + gfi;
@@ -1506,7 +1519,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         if (!optimise) nonfin = bad_state; // (dp_forward returns no latent: its frame results are NaN exactly when the state was refused)
         if (lane < FPW && f0 + lane < nB)
             GM(ae.status)[row0 + f0_e + lane_e] = (int)(((nonfin >> lane) & 1u) * DP_STATUS_NONFINITE_RESULT + ((bad_state >> lane) & 1u) * DP_STATUS_BAD_STATE +
-                                                        ((bad_tgt >> lane) & 1u) * DP_STATUS_BAD_TARGETS);
+                                                        ((bad_tgt >> lane) & 1u) * DP_STATUS_BAD_TARGETS + ((not_rot >> lane) & 1u) * DP_STATUS_TARGET_NOT_ROTATION);
     }
     SQ_STAMP(3);
     if (SEQ) { // the rest of run()'s epilogue (drag_pose.py:369-391), one lane per sequence: dp_sequence_advance's arithmetic

@@ -195,6 +195,13 @@ typedef struct dp_result {
 #define DP_STATUS_BAD_TARGETS 4      /* a tracked joint's target / weight, or z_tgt, not finite or beyond DP_INPUT_LIMIT: z and loss are
                                         NaN; with early_stop (or n_iter == 1) the pose results are those of the warm start z0 after ONE
                                         pass, as the reference returns them; without, NaN */
+#define DP_STATUS_TARGET_NOT_ROTATION 8 /* (0.5.1) a tracked joint's tgt_rot is not a rotation matrix (rows orthonormal within DP_ROTATION_TOL,
+                                        determinant positive).  The reference's rotation loss is an element-wise MSE on ANY 3 x 3 (drag_pose.py:
+                                        121-124); the kernels use its quaternion form, which equals it for rotations only -- every reference
+                                        caller passes rotations (eval_drag.py:199, run_drag.py:136).  The frame is computed as given (the matrix
+                                        read as the rotation Shepperd's conversion makes of it): a report, not a refusal; costs the set-up six
+                                        dot products per tracker, the loop nothing, the caller no synchronisation */
+#define DP_ROTATION_TOL 1.0e-3f
 #define DP_INPUT_LIMIT 1.0e4f        /* metres / weight units / latent units: keeps every intermediate of the loop finite in fp32 */
 
 int dp_version(void);

@@ -166,3 +166,70 @@ def test_clock_word_reports_a_plausible_shader_clock():
             out = opt.optimize(**d, n_iter=50, kernel=kernel, outputs=("z", "clock"))
         g = sclk_ghz(out["clock"])
         assert 0.5 < g < 2.6, (kernel, g, out["clock"].tolist())
+
+
+@pytest.mark.parametrize("kernel", ["w4", "w16"])
+def test_a_target_that_is_no_rotation_is_reported_at_the_abi(kernel):
+    """include/dragposer.h, DP_STATUS_TARGET_NOT_ROTATION: the reference's rotation loss is an element-wise MSE on any 3 x 3 (drag_pose.py:121-124),
+    the kernels' quaternion form equals it for rotation matrices only -- so where the kernel turns a tracked target into a quaternion it checks that
+    the matrix IS one (R^T R = I within DP_ROTATION_TOL, det > 0) and says so per frame; no refusal (the frame is computed as given), no hidden
+    synchronisation, every other frame bit-identical, untracked joints' matrices never looked at."""
+    from dragposer_amd import _lib
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    opt = LatentOptimizer(device="cuda:0")
+    d = _batch()
+    kw = dict(n_iter=20, lambda_tmp=0.02, kernel=kernel, outputs=PER_FRAME)
+    clean = opt.optimize(**d, **kw)
+    assert (clean["status"] == 0).all()
+    bad = dict(d)
+    bad["tgt_rot"] = d["tgt_rot"].clone()
+    bad["tgt_rot"][7, 13] *= 1.05                                  # a scaled rotation on a tracked joint (left hand) of frame 7
+    bad["tgt_rot"][30, 0, 0:3] = bad["tgt_rot"][30, 0, 3:6]        # a singular matrix (two equal rows) on the root tracker of frame 30
+    bad["tgt_rot"][44, 21] = -d["tgt_rot"][44, 21]                 # a reflection (determinant -1) on frame 44
+    bad["tgt_rot"][50, 2] = 3.0                                    # an UNTRACKED joint of frame 50: never read
+    bad["tgt_rot"][12, 17] += 2.0e-4                               # within the tolerance: rounding of a caller's own conversion is not reported
+    out = opt.optimize(**bad, **kw)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy()
+    hit = [7, 30, 44]
+    assert all(st[f] == _lib.DP_STATUS_TARGET_NOT_ROTATION for f in hit), st[hit]
+    others = [i for i in range(64) if i not in hit + [12]]
+    assert (st[others] == 0).all() and st[12] == 0
+    _rows_equal(out, clean, others)
+    for f in hit:  # computed as given: finite results
+        assert torch.isfinite(out["z"][f]).all() and torch.isfinite(out["pos"][f]).all()
+
+
+def test_a_sequence_step_with_a_non_rotation_target_says_so():
+    """the same word per step of a whole-sequence launch (dp_seq_results.status): step 2 of sequence 4 carries a scaled rotation target; that step of
+    that sequence says so, the sequence goes on (nothing is refused), the other sequences are bit-identical to the clean run"""
+    from dragposer_amd import _lib
+    from dragposer_amd.drag_pose import DragPose
+    from dragposer_amd.optimizer import LatentOptimizer
+
+    T, S = 5, 6
+    b = R.synth_inputs(R.OracleModel(), T * S, seed=77)
+    idx = np.array(R.TRACK6)
+    w = np.array([R.W6[j] for j in R.TRACK6], np.float32)
+    tp = torch.tensor(b["tgt_pos"][:, idx]).reshape(T, S, 6, 3).cuda()
+    tR = torch.tensor(b["tgt_rot"][:, idx]).reshape(T, S, 6, 3, 3).cuda()
+    opt = LatentOptimizer(device="cuda:0")
+    kw = dict(stop_eps_pos=1e-4, stop_eps_rot=1e-2, max_iter=20, min_loss_incr=1e-5, learning_rate=1e-2, lambda_rot=1, lambda_temporal=0.0,
+              temporal_future_window=0)
+
+    def fresh():
+        dp = DragPose(opt, None, np.zeros(24), np.ones(24), n_sequences=S)
+        dp.set_initial_state(b["z0"][:S], np.zeros((S, 3), np.float32), b["cur_rot"][:S], np.zeros((S, 6), np.float32))
+        return dp
+
+    a, c = fresh(), fresh()
+    pa, ga, ia = a.run_frames(tp, tR, idx, w, **kw)
+    tRb = tR.clone(); tRb[2, 4, 3] *= 1.1
+    pc, gc, ic = c.run_frames(tp, tRb, idx, w, **kw)
+    torch.cuda.synchronize()
+    want = np.zeros((T, S), np.int64)
+    want[2, 4] = _lib.DP_STATUS_TARGET_NOT_ROTATION
+    assert (np.asarray(c.last_status.cpu()) == want).all() and (a.last_status == 0).all(), c.last_status
+    ok = [s_ for s_ in range(S) if s_ != 4]
+    assert torch.equal(pc[:, ok], pa[:, ok]) and torch.equal(ic[:, ok], ia[:, ok]) and torch.isfinite(pc).all()
