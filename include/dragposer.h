@@ -34,7 +34,15 @@
  * parents[j] < j; at most 3 children of the root; at most 3 child bones beyond the first on all non-root joints together
  * (Xsens: the two shoulders and the neck branching off the upper spine use 2); kinematic chains of at most 7 bones from the
  * root.  The skeleton of the reference's data (the Xsens hierarchy every .bvh under python/data has, train.py:75-97)
- * satisfies all four.
+ * satisfies all four.  What kind of limit each one is (tests/test_hip_topology.py runs two other trees inside them through DP_KERNEL_W4):
+ *   22 joints               the MODEL: the decoder's widths 24 -> 40 -> 60 -> 92 = 22 x 4 + 4 are the checkpoint's (a layout constant of every kernel)
+ *   <= 3 root children      a table size (the root's children have constant root-frame bones, stored by item quads 0..2): raising it costs nothing
+ *                           in the loop
+ *   <= 3 extra child bones  a layout constant WITH A PRICE: every extra child bone is a "virtual" item whose decoder rows are a copy of its joint's,
+ *                           i.e. four more K-steps of the transposed last layer (K = 92 + 12 today); the item map has room for 8
+ *   chains of <= 7 bones    a table size with a price: a tracker sums the bones of its path in one pass of 7 LDS reads (two 32-bit path words hold 12)
+ * DP_KERNEL_W16's register slot map IS the reference's tree (four lane groups = left leg | right leg + lower spine | left arm + upper spine | right
+ * arm + head): any other parents array gets DP_ERR_UNSUPPORTED from it and DP_KERNEL_W4 from DP_KERNEL_AUTO.
  */
 #ifndef DRAGPOSER_H
 #define DRAGPOSER_H
