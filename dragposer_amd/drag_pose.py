@@ -195,6 +195,14 @@ class DragPose:
                                         tgt_rot=torch.zeros(S, NJ, 9, device=dev))
         return self._trk_cache[key]
 
+    @property
+    def temporal_status(self):
+        """DP_TEMPORAL_* bits of the native predictor's handle, read without synchronising (0 without one): 1 once a team of workgroups of an earlier
+        prediction gave up waiting for a member -- that prediction's targets are NaN for the affected sequences (their frames then carry
+        DP_STATUS_BAD_TARGETS in last_status), and the next prediction raises DragPoserError(DP_ERR_TIMEOUT) once before the operator goes on
+        with one workgroup per sequence (include/dragposer.h: dp_temporal_status)"""
+        return self._native_temporal.status() if self._native_temporal is not None else 0
+
     def run_frames(self, target_ee_pos, target_ee_rot, mask_joints, weights_joints, target_root=None, stop_eps_pos=1e-2, stop_eps_rot=1e-2,
                    max_iter=100, min_loss_incr=0.00001, learning_rate=1e-3, lambda_rot=1, lambda_temporal=1, temporal_future_window=60,
                    height_indices=(0, 4, 8, 13, 17, 21), joint_adjustment_indices=None, joint_adjustment_weight=0.01):

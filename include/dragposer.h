@@ -51,7 +51,9 @@
 extern "C" {
 #endif
 
-#define DP_VERSION 500 /* 0.5.0: ABI BREAK, the last one of this kind: dp_params and dp_result now START with `struct_size` (sizeof the
+#define DP_VERSION 510 /* 0.5.1 (compatible with 0.5.0 callers: nothing moved, nothing grew): dp_temporal_status, DP_ERR_TIMEOUT,
+                          DP_STATUS_TARGET_NOT_ROTATION, DP_KERNEL_W16 for n_iter > 256.
+                          0.5.0: ABI BREAK, the last one of this kind: dp_params and dp_result now START with `struct_size` (sizeof the
                           struct as the caller compiled it), so a caller built against another version of this header is DETECTED
                           (DP_ERR_INVALID with a message naming both sizes) instead of read past; fields appended later are read only
                           when struct_size covers them and take their defaults (0 / NULL) otherwise.  dp_result grew `status` (per-frame

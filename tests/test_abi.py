@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.dp_version() == 500
+    assert lib.dp_version() == 510
 
 
 def test_struct_layouts_match_header_sizes(tmp_path):

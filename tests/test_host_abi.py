@@ -73,7 +73,7 @@ def test_exports_every_symbol_of_the_header(lib):
     hdr = open(os.path.join(ROOT, "include", "dragposer.h")).read()
     for sym in set(re.findall(r"^(?:int|const char\*)\s+(dp_\w+)\s*\(", hdr, flags=re.M)):
         assert hasattr(lib, sym), sym
-    assert lib.dp_version() == 500
+    assert lib.dp_version() == 510
     assert "libdragposer_hostonly" not in open(os.path.join(ROOT, "dragposer_amd", "_lib.py")).read()  # the product does not know it
 
 
