@@ -70,7 +70,7 @@ def synth_on_device(opt, B, seed, device, lo=0, hi=None, mixed=False):
                 w=w, tracked=tracked)
 
 
-PMC_FILE = "profiles/r05_pmc_per_launch.json"
+PMC_FILE = "profiles/r06_pmc_per_launch.json"
 
 
 def pmc_traffic_bytes(frames, iters):

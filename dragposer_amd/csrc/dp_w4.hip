@@ -1496,8 +1496,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
         out_consts(lds + L_OC + 20 * b, item_eA, pc.tab == FB_RT ? KIND_ROOT : KIND_JOINT, item_eB, pc.kindB, oA, oB);
         if (fvalid || SEQ) { // (SEQ: the clamped copies of a ragged tail keep their own state consistent; their stores are skipped below)
             const Q4 cur = {cve.x, cve.y, cve.z, cve.w};
+#ifndef W4_ABLATE_OUT // (diagnostic: the launch without its per-item result arrays -- what the epilogue costs)
             w4_outputs<SEQ>(ae, oA, fb, gfo, optimise, cur, tmask, EARLY, (pois_all >> i) & 1u, (pois_z >> i) & 1u); // (SEQ: the copies re-store the last valid frame's rows, same values)
             w4_outputs<SEQ>(ae, oB, fb, gfo, optimise, cur, tmask, EARLY, (pois_all >> i) & 1u, (pois_z >> i) & 1u);
+#endif
         }
     }
     SQ_STAMP(2);

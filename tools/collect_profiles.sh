@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r05/).
+# Regenerates the files under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/prof_r06/).
 # rocprofv3: program directly after `--`; counters in their own passes with --kernel-trace only.
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/prof_r05
+O=gpurun_out/prof_r06
 rm -rf $O && mkdir -p $O
 # 1. kernel-trace stats of the default bench command
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --no-cpu-baseline --traffic file > $O/bench_under_rocprof.json 2> $O/stats.log
@@ -72,4 +72,12 @@ if ls _scratch/lib_ab_*.so > /dev/null 2>&1; then LIBS="$(ls _scratch/lib_ab_*.s
 if [ -f _scratch/lib_noskip.so ]; then REPS=3 python3 tools/ab_configs.py _scratch/lib_noskip.so dragposer_amd/lib/libdragposer_hip.so > $O/b2_skip_ab.txt 2>&1 || true; fi
 python3 tools/clip_twins.py f1_clip4 f1_clip4_t 2>/dev/null | grep -v "^Mean\|^Time\|^Evaluate\|^Frames" > $O/clip_twins.txt || true
 echo "round-5 probes done"
+# 12. round 6: the headline launch's slope and intercept at the steady clock; L0's sub-phases pinned to the arrival of their results; the temporal
+#     kernel's PAIR variant against the two-workgroups-per-CU one; the epilogue's share (library built by tools/build_variant_w4.sh ... -DW4_ABLATE_OUT)
+python3 tools/launch_intercept.py dragposer_amd/lib/libdragposer_hip.so 2>&1 | grep -v amdgpu.ids > $O/launch_intercept.txt || true
+if [ -f _scratch/lib_noout.so ]; then python3 tools/launch_intercept.py _scratch/lib_noout.so 2>&1 | grep -v amdgpu.ids >> $O/launch_intercept.txt || true; fi
+( EXTRA_DEFS=-DW4_STAMP_L0 PHASE_L0=1 SPECS="4096:0:w4" bash tools/phase_profile.sh ) > $O/phase_cycles_L0.txt 2>&1 || true
+python3 tools/ab_temporal_variants.py 42,44 2>&1 | grep "^window" > $O/temporal_pair_ab.txt || true
+if [ -f _scratch/lib_nopk.so ]; then LIBS="_scratch/lib_nopk.so dragposer_amd/lib/libdragposer_hip.so" REPS=4 bash tools/ab.sh > $O/packed_adam_ab.txt 2>&1 || true; fi
+echo "round-6 probes done"
 ls $O
