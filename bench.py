@@ -319,17 +319,20 @@ def main():
         torch.cuda.synchronize()
         # (the step as a caller that reuses its buffers issues it: arguments marshalled once, LatentOptimizer.plan -- one dp_optimize call per step)
         step = opt.plan(**batch, n_iter=N, outputs=names, out=out, kernel=kernel)
-        # what a caller who submits ONE batch to an idle GPU gets: after >= 100 ms without work, one launch between two events, read back with the
+        # what a caller who submits ONE batch to an idle GPU gets: after 150 ms without work, one launch between two events (three times: the median), with the
         # clock it ran at (the DVFS floor, 2.08-2.10 GHz).  Reported beside the steady figures (roofline.*_from_idle); never part of `value`.
         idle = None
         if from_idle:
-            time.sleep(0.15)
-            i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            i0.record()
-            step()
-            i1.record()
-            torch.cuda.synchronize()
-            idle = (i0.elapsed_time(i1), sclk_ghz(out["clock"]))
+            tries = []
+            for _ in range(3):  # (the median of three: the first launch after a pause also pays whatever the runtime let go idle)
+                time.sleep(0.15)
+                i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                i0.record()
+                step()
+                i1.record()
+                torch.cuda.synchronize()
+                tries.append((i0.elapsed_time(i1), sclk_ghz(out["clock"])))
+            idle = sorted(tries)[1]
         if args.precondition_ms > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -267,13 +267,13 @@ DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 // q | k | v = in_proj(xq | xkv | xkv) in ONE phase: the nine 16-row tiles of the packed in_proj weight [144][48] (x token
 // tiles) are dealt to the waves; output channels 0..47 take the query tokens, the rest the key / value tokens.
 template <int NS>
-DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* W, const float* b)
-{ // (q rows in the layout of rows_per_seq(Tq) rows per sequence, k / v rows in that of rows_per_seq(Tk))
+DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, const float* W, const float* b, bool v_only = false)
+{ // (q rows in the layout of rows_per_seq(Tq) rows per sequence, k / v rows in that of rows_per_seq(Tk); v_only (uniform): the three value tiles alone -- mha)
     const int Rq = rows_per_seq<NS>(Tq), Rk = rows_per_seq<NS>(Tk);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin)
     const int wave = lwave(), l16 = lane & 15, qd = lane >> 4;
-    const int ttq = n_ttiles<NS>(Tq, Rq), ttk = n_ttiles<NS>(Tk, Rk), jobs = 3 * ttq + 6 * ttk;
+    const int ttq = v_only ? 0 : n_ttiles<NS>(Tq, Rq), ttk = n_ttiles<NS>(Tk, Rk), jobs = 3 * ttq + (v_only ? 3 : 6) * ttk;
     // a wave takes its jobs two at a time -- job and job + 8 (with nine jobs only wave 0 has a second one): both jobs' operands are requested
     // before the first product (a weight row comes from cold memory: the second round trip is what the other seven waves would wait for)
 #pragma unroll 1
@@ -286,7 +286,7 @@ DEV void lin_qkv(float* qkv, const float* xq, int Tq, const float* xkv, int Tk, 
         for (int u = 0; u < 2; ++u) {
             const int job = job0 + u * NWV;
             const bool isq = job < 3 * ttq;
-            const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : j2 / 6;
+            const int j2 = isq ? job : job - 3 * ttq, nt = isq ? j2 % 3 : v_only ? 6 + j2 % 3 : 3 + j2 % 6, tt = isq ? j2 / 3 : v_only ? j2 / 3 : j2 / 6;
             const float* in = isq ? xq : xkv;
             const int Tj = isq ? Tq : Tk, Rj = isq ? Rq : Rk, n = 16 * nt + l16;
             nn[u] = n; tts[u] = tt; isqs[u] = isq;
@@ -394,6 +394,14 @@ template <int NS>
 DEV void mha(float* o, const float* xq, int Tq, const float* xkv, int Tk, const float* w, int in_wT, int in_b, int out_wT, int out_b,
              float* q, float* k, float* v, float* ao, float* sc)
 {
+    if (xq == xkv && Tq == 1) { // (uniform) ONE token attending to itself -- the first decoder call of every block: the softmax over one key is exactly 1
+        // (exp(0) / 1), the head outputs ARE the value rows (fma(1, v, 0)), bit for bit: no query, no key, no attention phase
+        lin_qkv<NS>(q, xq, Tq, xkv, Tk, w + in_wT, w + in_b, true);
+        STAMP(1);
+        lin<D / 4, NS>(o, D, v, D, Tq, w + out_wT, w + out_b, D, D);
+        STAMP(3);
+        return;
+    }
     lin_qkv<NS>(q, xq, Tq, xkv, Tk, w + in_wT, w + in_b);
     STAMP(1);
     attention<NS>(ao, q, k, v, sc, Tq, Tk);
@@ -1328,11 +1336,11 @@ extern "C" int dp_temporal_predict(dp_temporal* t, int n_seq, const dp_seq_state
     // workgroup when each has at most 16 tokens (every weight fetch then serves both)
     const bool pair_ok = n_past - 1 <= 16 && n_steps <= 16;
     // (44 = PAIR, one 1024-thread workgroup of two NS = 2 halves per CU that share the weight fetches of the feed-forward layers in calls over at
-    //  most 8 tokens.  Measured at 1024 / 4096 sequences, profiles/r06_temporal_pair_ab.txt: window 16 (five decoder calls of 1 .. 5 tokens) -11.5 %;
-    //  window 0 and window 60 +-1 % -- what the shared fetches save there, the halves' lock-step gives back: two independent workgroups on a CU
-    //  drift apart and run one's small phases under the other's tile loop.  So: where EVERY decoder call has at most 8 tokens and there are at least
-    //  two of them, and variant 42 would put two workgroups on a CU anyway.)
-    int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? ((n_seq > 2 * t->n_cu && n_steps >= 2 && n_steps <= 8) ? 44 : 42) : 41);
+    //  most 8 tokens.  Measured at 1024 / 4096 sequences, profiles/r06_temporal_pair_ab.txt: window 16 (five decoder calls of 1 .. 5 tokens) -12.8 %
+    //  / -12.8 %; window 0 -3.1 % / -1.2 %; window 60 -2.7 % / -2.4 % -- there most of what the shared fetches save is given back by the halves'
+    //  lock-step: two independent workgroups on a CU drift apart and run one's small phases under the other's tile loop.  Taken wherever variant 42
+    //  would put two workgroups on a CU anyway.)
+    int variant = n_seq <= t->n_cu ? 21 : (pair_ok ? (n_seq > 2 * t->n_cu ? 44 : 42) : 41);
     // few sequences: a TEAM of G workgroups per sequence (the largest power of two up to 16 with every workgroup on a CU of its own -- they wait for
     // each other, so all of them must be resident -- and at least one feed-forward tile per wave)
     // (the CUs this launch may use: the device's, or the stream's CU mask when it has one -- hipExtStreamGetCUMask reports the effective mask)
