@@ -238,27 +238,35 @@ DEV float wave_sum(float v)
            (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
 
-// x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm): one wave per token, one
-// lane per channel
+// x[t] = LayerNorm(x[t] + o[t]) (o may be null), eps 1e-5, biased variance (torch.nn.LayerNorm).  Round 6: FOUR tokens per wave, one per DPP row of
+// 16 lanes, three channels per lane (c = l16 + 16 j: a row's lanes read consecutive words) -- both sums are three adds and a register-to-register
+// row reduction, no scalar round trip (the one-token-per-wave form went through v_readlane twice per token and took two turns for a 14-token
+// encoder pass: 17 LayerNorms stand in every block's latency chain).
 template <int NS>
 DEV void add_ln(float* x, const float* o, int T, const float* g, const float* b)
 {
     const int R = rows_per_seq<NS>(T);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in lin: the per-lane addresses of the two parameter rows are not to be hoisted out of the call loop and spilled)
-    const int wave = lwave();
-    const bool live = lane < D;
-    const float gc = live ? g[lane] : 0.f, bc = live ? b[lane] : 0.f;
+    const int wave = lwave(), l16 = lane & 15, r4 = lane >> 4;
+    float gc[3], bc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gc[k] = g[l16 + 16 * k]; bc[k] = b[l16 + 16 * k]; }
     const int rows = 16 * n_ttiles<NS>(T, R);
 #pragma unroll 1
-    for (int t = wave; t < rows; t += NWV) {
-        if (!row_valid<NS>(t, T, R)) continue; // (uniform per wave)
-        float v = 0.f;
-        if (live) v = x[t * D + lane] + (o ? o[t * D + lane] : 0.f);
-        const float mean = wave_sum(v) * (1.f / D);
-        const float d = live ? v - mean : 0.f;
-        const float r = 1.f / sqrtf(wave_sum(d * d) * (1.f / D) + 1e-5f);
-        if (live) x[t * D + lane] = d * r * gc + bc;
+    for (int t0 = 4 * wave; t0 < rows; t0 += 4 * NWV) {
+        const int t = t0 + r4;
+        if (t < rows && row_valid<NS>(t, T, R)) { // (per DPP row: the reductions below stay inside a row)
+            float v[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = x[t * D + l16 + 16 * k] + (o ? o[t * D + l16 + 16 * k] : 0.f);
+            const float mean = row_sum((v[0] + v[1]) + v[2]) * (1.f / D);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean;
+            const float r = 1.f / sqrtf(row_sum((d0 * d0 + d1 * d1) + d2 * d2) * (1.f / D) + 1e-5f);
+            x[t * D + l16] = d0 * r * gc[0] + bc[0];
+            x[t * D + l16 + 16] = d1 * r * gc[1] + bc[1];
+            x[t * D + l16 + 32] = d2 * r * gc[2] + bc[2];
+        }
     }
     STAMP(25);
     __syncthreads();
