@@ -1086,8 +1086,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dp_w4_kernel(const KArgs a)
     //      64 cycles apart -- about a quarter of an iteration: each wave's kinematics window falls into the others' matrix phases -- the launch is
     //      5-7 % shorter on every configuration (profiles/r05_stagger_sweep.txt: 12 ... 36, seven workloads, six rounds each; 18 ... 22 is the
     //      flat optimum, 20 the most even), the three sleeps included.  Outputs unchanged (a wave's arithmetic does not know when it runs).
+//      Round 6, after Adam's packing shortened the iteration by ~130 cycles: 18 beats 20 on all seven workloads (-0.1 ... -0.7 %, four rounds each,
+//      two boxes; 16 and 22 lose on the 100-iteration ones): profiles/r06_stagger_sweep.txt.
 #ifndef W4_STAGGER
-#define W4_STAGGER 20
+#define W4_STAGGER 18
 #endif
     if (W4_STAGGER > 0 && optimise)
         for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(W4_STAGGER);
