@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the temporal kernel's team exchange: launches of random sequence counts (1 ... 128: team sizes 16 / 8 / 4 / 2 in turn over ONE exchange area),
+"""Soak of the temporal kernel's team exchange: launches of random sequence counts (1 ... 128: team sizes 8 / 4 / 2 / none in turn over ONE exchange area),
 random windows and inputs, back to back; every launch compared with the one-workgroup-per-sequence kernel on the same inputs, the handle's status word
 read at the end.  Usage: tools/team_soak.py [seconds=60]"""
 import os, sys, time
@@ -33,7 +33,7 @@ while time.time() - t0 < seconds:
     err = float((outs[0] - want).abs().max())
     assert err <= 1e-5, (S, window, err)
     worst = max(worst, err)
-    G = 16 if S * 64 <= 256 else 8 if S * 16 <= 256 else 4 if S * 8 <= 256 else 2
+    G = int(team._lib.dp_temporal_debug_team_size(256, S, 2048))  # (the library's own rule: all teams of a launch on at most half the CUs)
     by_size[G] = by_size.get(G, 0) + reps
     n += reps
 assert team._team_status() == 0
